@@ -1,0 +1,69 @@
+# -*- coding: utf-8 -*-
+"""ctypes binding of libdmn_hip.so (the C ABI declared in include/dmn_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or does not export a
+symbol, importing the ops fails loudly -- a silently slower (or CPU) path would void every
+parity and performance claim made for the HIP kernels.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("DMN_HIP_LIB", os.path.join(_HERE, "lib", "libdmn_hip.so"))
+ABI_VERSION = 1
+
+_p = ctypes.c_void_p
+_i = ctypes.c_int
+_f = ctypes.c_float
+
+# name -> argtypes, mirrors include/dmn_hip.h one to one
+SIGNATURES = {
+    "dmn_sru_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p],
+    "dmn_sru_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
+    "dmn_sru_fwd_scan": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _p],
+    "dmn_sru_scan_workspace_floats": [_i, _i, _i, _i],
+    "dmn_cat_coords": [_p, _p, _i, _i, _i, _i, _p],
+    "dmn_dynfilter_fwd": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "dmn_dynfilter_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "dmn_mix_bcast_add": [_p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p],
+    "dmn_mix_bcast_add_bwd": [_p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "dmn_cat_upsample2x": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "dmn_cat_upsample2x_bwd": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and type the library; raises if it is absent or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "dms_amd: %s not found. Build it with `python -m dms_amd.build` "
+            "(hipcc --offload-arch=gfx950); there is no fallback path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.dmn_abi_version.restype = _i
+    lib.dmn_last_error.restype = ctypes.c_char_p
+    got = lib.dmn_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError("dms_amd: libdmn_hip.so has ABI %d, python side expects %d; rebuild"
+                           % (got, ABI_VERSION))
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing: loud
+        fn.argtypes = argtypes
+        fn.restype = _i
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Invoke an entry point; non-zero status -> RuntimeError(dmn_last_error())."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.dmn_last_error()
+        raise RuntimeError("%s failed (status %d): %s"
+                           % (name, rc, msg.decode("utf-8", "replace") if msg else "?"))
+    return rc

@@ -1,0 +1,67 @@
+// dms_amd/csrc/common.h -- shared helpers for libdmn_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/dmn_hip.h"
+
+namespace dmn {
+
+// thread-local message of the last failure, exposed through dmn_last_error()
+char *err_buf();
+int fail(int code, const char *fmt, ...);
+
+inline int launch_status(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail((int)e, "%s: %s", what, hipGetErrorString(e));
+    return 0;
+}
+
+constexpr int WAVE = 64;          // CDNA wavefront
+constexpr int NUM_CU = 256;       // MI355X
+
+__device__ __forceinline__ float fast_exp2(float v) { return __builtin_amdgcn_exp2f(v); }
+__device__ __forceinline__ float fast_rcp(float v) { return __builtin_amdgcn_rcpf(v); }
+
+// 1 / (1 + 2^(-v*log2 e)): one v_exp_f32 + one v_rcp_f32 (both ~1 ulp)
+__device__ __forceinline__ float sigmoid_f(float v)
+{
+    return fast_rcp(1.0f + fast_exp2(v * -1.4426950408889634f));
+}
+
+// tanh with ~2e-7 relative error everywhere: odd polynomial below 0.125 (where the
+// exp form cancels), (1 - e) / (1 + e), e = exp(-2|v|), above.
+__device__ __forceinline__ float tanh_f(float v)
+{
+    const float a = __builtin_fabsf(v);
+    const float e = fast_exp2(a * -2.8853900817779268f);
+    const float big = (1.0f - e) * fast_rcp(1.0f + e);
+    const float a2 = a * a;
+    float p = __builtin_fmaf(a2, 0.021869488536155203f, -0.053968253968253968f);
+    p = __builtin_fmaf(a2, p, 0.13333333333333333f);
+    p = __builtin_fmaf(a2, p, -0.33333333333333333f);
+    p = __builtin_fmaf(a2 * a, p, a);
+    const float r = a < 0.125f ? p : big;
+    return __builtin_copysignf(r, v);
+}
+
+template <int ACT>
+__device__ __forceinline__ float act_fwd(float v)
+{
+    if (ACT == DMN_ACT_TANH) return tanh_f(v);
+    if (ACT == DMN_ACT_RELU) return v > 0.0f ? v : 0.0f;
+    return v;
+}
+
+// derivative expressed through the activation OUTPUT y
+template <int ACT>
+__device__ __forceinline__ float act_bwd(float y)
+{
+    if (ACT == DMN_ACT_TANH) return 1.0f - y * y;
+    if (ACT == DMN_ACT_RELU) return y > 0.0f ? 1.0f : 0.0f;
+    return 1.0f;
+}
+
+}  // namespace dmn

@@ -1,0 +1,197 @@
+// dms_amd/csrc/glue.hip -- concat / coordinate / bilinear-x2 glue kernels (gfx950).
+//
+//  dmn_cat_coords        : dmn.py:142 + 225-246   (coordinate channels written on device)
+//  dmn_cat_upsample2x    : dmn.py:324,337-338     (cat + nn.Upsample(x2, bilinear) in one pass)
+//
+// All of these are pure HBM streaming: one 16-byte store per lane, inputs re-read from
+// L1/L2 (each input element feeds 4 outputs of the x2 upsample).
+#include "common.h"
+
+namespace dmn {
+
+// coordinate channel `ch` at (h, w): python-float (fp64) arithmetic in the reference's order
+__device__ __forceinline__ float coord_val(int ch, int h, int w, int H, int W)
+{
+    const double xmin = (double)w / W * 2 - 1, xmax = (double)(w + 1) / W * 2 - 1;
+    const double ymin = (double)h / H * 2 - 1, ymax = (double)(h + 1) / H * 2 - 1;
+    switch (ch) {
+        case 0: return (float)xmin;
+        case 1: return (float)ymin;
+        case 2: return (float)xmax;
+        case 3: return (float)ymax;
+        case 4: return (float)((xmin + xmax) / 2);
+        case 5: return (float)((ymin + ymax) / 2);
+        case 6: return (float)(1.0 / W);
+        default: return (float)(1.0 / H);
+    }
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(256)
+cat_coords_kernel(const float *__restrict__ vis, float *__restrict__ V, int B, int C, int H, int W)
+{
+    const int S = H * W, Sv = S / VEC, C8 = C + 8;
+    const long long total = (long long)B * C8 * Sv;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int sv = (int)(i % Sv);
+        const long long plane = i / Sv;
+        const int c = (int)(plane % C8);
+        const int b = (int)(plane / C8);
+        float *dst = V + plane * S + (long long)sv * VEC;
+        if (c < C) {
+            const float *src = vis + ((long long)b * C + c) * S + (long long)sv * VEC;
+            if (VEC == 4) *reinterpret_cast<float4 *>(dst) = *reinterpret_cast<const float4 *>(src);
+            else *dst = *src;
+        } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const int s = sv * VEC + e;
+                dst[e] = coord_val(c - C, s / W, s % W, H, W);
+            }
+        }
+    }
+}
+
+// PyTorch's area_pixel_compute_source_index for align_corners=False, scale 1/2
+__device__ __forceinline__ void src_index(int o, int n_in, int &i0, int &i1, float &l0, float &l1)
+{
+    float s = 0.5f * ((float)o + 0.5f) - 0.5f;
+    s = s < 0.0f ? 0.0f : s;
+    i0 = (int)s;
+    i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+    l1 = s - (float)i0;
+    l0 = 1.0f - l1;
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(256)
+cat_upsample2x_kernel(const float *__restrict__ x, const float *__restrict__ feat,
+                      float *__restrict__ out, int B, int Cx, int Cf, int H, int W)
+{
+    const int Ct = Cx + Cf, OH = 2 * H, OW = 2 * W, OWv = OW / VEC;
+    const long long total = (long long)B * Ct * OH * OWv;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int oxv = (int)(i % OWv);
+        long long r = i / OWv;
+        const int oy = (int)(r % OH);
+        r /= OH;
+        const int c = (int)(r % Ct);
+        const int b = (int)(r / Ct);
+        const float *src = (c < Cx) ? x + ((long long)b * Cx + c) * H * W
+                                    : feat + ((long long)b * Cf + (c - Cx)) * H * W;
+        int y0, y1; float ly0, ly1;
+        src_index(oy, H, y0, y1, ly0, ly1);
+        const float *r0 = src + (long long)y0 * W, *r1 = src + (long long)y1 * W;
+        float res[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            int x0, x1; float lx0, lx1;
+            src_index(oxv * VEC + e, W, x0, x1, lx0, lx1);
+            res[e] = ly0 * (lx0 * r0[x0] + lx1 * r0[x1]) + ly1 * (lx0 * r1[x0] + lx1 * r1[x1]);
+        }
+        float *dst = out + (((long long)b * Ct + c) * OH + oy) * OW + (long long)oxv * VEC;
+        if (VEC == 4) *reinterpret_cast<float4 *>(dst) = make_float4(res[0], res[1], res[2], res[3]);
+        else dst[0] = res[0];
+    }
+}
+
+// gather form of the transpose: every input pixel sums the <= 4x4 outputs that read it
+__global__ void __launch_bounds__(256)
+cat_upsample2x_bwd_kernel(const float *__restrict__ g, float *__restrict__ gx,
+                          float *__restrict__ gfeat, int B, int Cx, int Cf, int H, int W)
+{
+    const int Ct = Cx + Cf, OH = 2 * H, OW = 2 * W;
+    const long long total = (long long)B * Ct * H * W;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % W);
+        long long r = i / W;
+        const int yy = (int)(r % H);
+        r /= H;
+        const int c = (int)(r % Ct);
+        const int b = (int)(r / Ct);
+        float *dst = (c < Cx) ? gx : gfeat;
+        if (!dst) continue;
+        const float *gp = g + ((long long)b * Ct + c) * OH * OW;
+        float acc = 0.0f;
+        const int oy_lo = max(2 * yy - 1, 0), oy_hi = min(2 * yy + 2, OH - 1);
+        const int ox_lo = max(2 * xx - 1, 0), ox_hi = min(2 * xx + 2, OW - 1);
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            int y0, y1; float ly0, ly1;
+            src_index(oy, H, y0, y1, ly0, ly1);
+            const float wy = (y0 == yy ? ly0 : 0.0f) + (y1 == yy ? ly1 : 0.0f);
+            if (wy == 0.0f) continue;
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                int x0, x1; float lx0, lx1;
+                src_index(ox, W, x0, x1, lx0, lx1);
+                const float wx = (x0 == xx ? lx0 : 0.0f) + (x1 == xx ? lx1 : 0.0f);
+                acc += wy * wx * gp[(long long)oy * OW + ox];
+            }
+        }
+        const long long o = (c < Cx) ? (((long long)b * Cx + c) * H + yy) * W + xx
+                                     : (((long long)b * Cf + (c - Cx)) * H + yy) * W + xx;
+        dst[o] = acc;
+    }
+}
+
+static int stream_grid(long long work_items)
+{
+    long long blocks = (work_items + 255) / 256;
+    const long long cap = (long long)NUM_CU * 16;   // grid-stride beyond 16 blocks per CU
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+}  // namespace dmn
+
+using namespace dmn;
+
+extern "C" int dmn_cat_coords(const float *vis, float *V, int B, int C, int H, int W, void *stream)
+{
+    if ((!vis && C > 0) || !V) return fail(-1, "dmn_cat_coords: NULL pointer");
+    if (B <= 0 || C < 0 || H <= 0 || W <= 0) return fail(-4, "dmn_cat_coords: bad sizes B=%d C=%d H=%d W=%d", B, C, H, W);
+    const int S = H * W;
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = (S % 4 == 0) && !(((uintptr_t)vis | (uintptr_t)V) & 15);
+    if (vec) {
+        const long long n = (long long)B * (C + 8) * (S / 4);
+        hipLaunchKernelGGL(cat_coords_kernel<4>, dim3(stream_grid(n)), dim3(256), 0, s, vis, V, B, C, H, W);
+    } else {
+        const long long n = (long long)B * (C + 8) * S;
+        hipLaunchKernelGGL(cat_coords_kernel<1>, dim3(stream_grid(n)), dim3(256), 0, s, vis, V, B, C, H, W);
+    }
+    return launch_status("dmn_cat_coords");
+}
+
+extern "C" int dmn_cat_upsample2x(const float *x, const float *feat, float *out, int B, int Cx,
+                                  int Cf, int H, int W, void *stream)
+{
+    if (!out || (Cx > 0 && !x) || (Cf > 0 && !feat)) return fail(-1, "dmn_cat_upsample2x: NULL pointer");
+    if (B <= 0 || Cx < 0 || Cf < 0 || Cx + Cf <= 0 || H <= 0 || W <= 0)
+        return fail(-4, "dmn_cat_upsample2x: bad sizes B=%d Cx=%d Cf=%d H=%d W=%d", B, Cx, Cf, H, W);
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = ((2 * W) % 4 == 0) && !((uintptr_t)out & 15);
+    if (vec) {
+        const long long n = (long long)B * (Cx + Cf) * (2 * H) * (2 * W / 4);
+        hipLaunchKernelGGL(cat_upsample2x_kernel<4>, dim3(stream_grid(n)), dim3(256), 0, s, x, feat, out, B, Cx, Cf, H, W);
+    } else {
+        const long long n = (long long)B * (Cx + Cf) * (2 * H) * (2 * W);
+        hipLaunchKernelGGL(cat_upsample2x_kernel<1>, dim3(stream_grid(n)), dim3(256), 0, s, x, feat, out, B, Cx, Cf, H, W);
+    }
+    return launch_status("dmn_cat_upsample2x");
+}
+
+extern "C" int dmn_cat_upsample2x_bwd(const float *g, float *gx, float *gfeat, int B, int Cx,
+                                      int Cf, int H, int W, void *stream)
+{
+    if (!g) return fail(-1, "dmn_cat_upsample2x_bwd: NULL gradient");
+    if (B <= 0 || Cx < 0 || Cf < 0 || Cx + Cf <= 0 || H <= 0 || W <= 0)
+        return fail(-4, "dmn_cat_upsample2x_bwd: bad sizes");
+    const long long n = (long long)B * (Cx + Cf) * H * W;
+    hipLaunchKernelGGL(cat_upsample2x_bwd_kernel, dim3(stream_grid(n)), dim3(256), 0,
+                       (hipStream_t)stream, g, gx, gfeat, B, Cx, Cf, H, W);
+    return launch_status("dmn_cat_upsample2x_bwd");
+}

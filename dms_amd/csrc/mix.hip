@@ -1,0 +1,211 @@
+// dms_amd/csrc/mix.hip -- concat-free 1x1 mix + reorder into the mSRU sequence (gfx950).
+//
+// Replaces dmn_pytorch/models/dmn.py:187-201: the (L, 4706, H, W) concat (96 MB/sample at
+// 512 px), the 4706->1000 comb_conv over it (24 GMAC) and the permute/contiguous into
+// sequence order n = s*L + t.  comb_conv is linear, so with its weight split by input
+// block  [vis+coords | WE | h | P]  the caller computes two small GEMMs (A: once per pixel,
+// Bt: once per word) and this kernel does the rank-K update and the broadcast add while
+// writing Q directly in (S*L, B, M) order:
+//     Q[(s*L + t), b, m] = A[b,s,m] + Bt[t,b,m] + sum_k Wp[m,k] * P[t,b,k,s]
+// Pure HBM write stream (Q = 20.5 MB/sample); A/Bt/P/Wp are re-read from L2.  One lane
+// owns 4 adjacent m (one 16-byte store per (s,t)); a wave writes 1 KiB contiguous.
+#include "common.h"
+
+namespace dmn {
+
+constexpr int MIX_PT = 4;      // pixels per workgroup
+constexpr int MIX_KMAX = 16;   // filters kept in registers
+
+__device__ __forceinline__ long long lbk_off(int t, int b, int k, int B, int K, int ld)
+{
+    return ((long long)(t * B + b) * K + k) * ld;
+}
+
+template <int VEC, bool KREG>
+__global__ void __launch_bounds__(256)
+mix_fwd_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
+               const float *__restrict__ P, const float *__restrict__ Wp, int ldw,
+               float *__restrict__ Q, int B, int L, int K, int S, int M)
+{
+    extern __shared__ float Ps[];            // [L*K][MIX_PT]
+    const int b = blockIdx.y, s0 = blockIdx.x * MIX_PT;
+    const int LK = L * K;
+    for (int idx = threadIdx.x; idx < LK * MIX_PT; idx += blockDim.x) {
+        const int r = idx / MIX_PT, pp = idx - r * MIX_PT;
+        const int t = r / K, k = r - t * K;
+        const int s = s0 + pp;
+        Ps[idx] = s < S ? P[lbk_off(t, b, k, B, K, S) + s] : 0.0f;
+    }
+    __syncthreads();
+
+    const int Mv = M / VEC;
+    for (int mv = threadIdx.x; mv < Mv; mv += blockDim.x) {
+        const int m = mv * VEC;
+        float w[VEC][KREG ? MIX_KMAX : 1];
+        if (KREG) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+#pragma unroll
+                for (int k = 0; k < MIX_KMAX; ++k)
+                    w[e][k] = k < K ? Wp[(long long)(m + e) * ldw + k] : 0.0f;
+        }
+        for (int pp = 0; pp < MIX_PT; ++pp) {
+            const int s = s0 + pp;
+            if (s >= S) break;
+            float a[VEC];
+            const float *Ap = A + ((long long)b * S + s) * M + m;
+            if (VEC == 4) { const float4 v = *reinterpret_cast<const float4 *>(Ap); a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w; }
+            else a[0] = Ap[0];
+            for (int t = 0; t < L; ++t) {
+                float q[VEC];
+                const float *Bp = Bt + ((long long)t * B + b) * M + m;
+                if (VEC == 4) { const float4 v = *reinterpret_cast<const float4 *>(Bp); q[0] = a[0] + v.x; q[1] = a[1] + v.y; q[2] = a[2] + v.z; q[3] = a[3] + v.w; }
+                else q[0] = a[0] + Bp[0];
+                if (KREG) {
+#pragma unroll
+                    for (int k = 0; k < MIX_KMAX; ++k) {
+                        if (k < K) {
+                            const float pv = Ps[(t * K + k) * MIX_PT + pp];
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) q[e] = __builtin_fmaf(w[e][k], pv, q[e]);
+                        }
+                    }
+                } else {
+                    for (int k = 0; k < K; ++k) {
+                        const float pv = Ps[(t * K + k) * MIX_PT + pp];
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e)
+                            q[e] = __builtin_fmaf(Wp[(long long)(m + e) * ldw + k], pv, q[e]);
+                    }
+                }
+                float *Qp = Q + (((long long)s * L + t) * B + b) * M + m;
+                if (VEC == 4) *reinterpret_cast<float4 *>(Qp) = make_float4(q[0], q[1], q[2], q[3]);
+                else Qp[0] = q[0];
+            }
+        }
+    }
+}
+
+// ---- backward A: per (b, pixel): gA[b,s,m] = sum_t gQ ; gP[t,b,k,s] = sum_m Wp[m,k] gQ ----
+__global__ void __launch_bounds__(256)
+mix_bwd_pix_kernel(const float *__restrict__ gQ, const float *__restrict__ Wp, int ldw,
+                   float *__restrict__ gA, float *__restrict__ gP, int B, int L, int K, int S, int M)
+{
+    __shared__ float red[4][MIX_KMAX];
+    const int b = blockIdx.y, s = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // lane-private accumulators for up to 4 strided m (M <= 1024)
+    float ga[4] = {0, 0, 0, 0};
+    for (int t = 0; t < L; ++t) {
+        float part[MIX_KMAX];
+#pragma unroll
+        for (int k = 0; k < MIX_KMAX; ++k) part[k] = 0.0f;
+        const float *g = gQ + (((long long)s * L + t) * B + b) * M;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = threadIdx.x + i * 256;
+            if (m < M) {
+                const float gv = g[m];
+                ga[i] += gv;
+#pragma unroll
+                for (int k = 0; k < MIX_KMAX; ++k)
+                    if (k < K) part[k] = __builtin_fmaf(Wp[(long long)m * ldw + k], gv, part[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < MIX_KMAX; ++k) {
+            if (k < K) {
+                float v = part[k];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                if (lane == 0) red[wave][k] = v;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < K)
+            gP[lbk_off(t, b, threadIdx.x, B, K, S) + s] =
+                red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = threadIdx.x + i * 256;
+        if (m < M) gA[((long long)b * S + s) * M + m] = ga[i];
+    }
+}
+
+// ---- backward B: per (t, b): gBt[t,b,m] = sum_s gQ ; gWp_part[t,b,m,k] = sum_s gQ * P ----
+__global__ void __launch_bounds__(256)
+mix_bwd_word_kernel(const float *__restrict__ gQ, const float *__restrict__ P,
+                    float *__restrict__ gBt, float *__restrict__ gWp_part,
+                    int B, int L, int K, int S, int M)
+{
+    extern __shared__ float Pt[];            // [K][S] for this (t, b)
+    const int t = blockIdx.x, b = blockIdx.y;
+    for (int idx = threadIdx.x; idx < K * S; idx += blockDim.x)
+        Pt[idx] = P[lbk_off(t, b, 0, B, K, S) + idx];
+    __syncthreads();
+    for (int m = threadIdx.x; m < M; m += blockDim.x) {
+        float gb = 0.0f, gw[MIX_KMAX];
+#pragma unroll
+        for (int k = 0; k < MIX_KMAX; ++k) gw[k] = 0.0f;
+        for (int s = 0; s < S; ++s) {
+            const float gv = gQ[(((long long)s * L + t) * B + b) * M + m];
+            gb += gv;
+#pragma unroll
+            for (int k = 0; k < MIX_KMAX; ++k)
+                if (k < K) gw[k] = __builtin_fmaf(gv, Pt[k * S + s], gw[k]);
+        }
+        gBt[((long long)t * B + b) * M + m] = gb;
+#pragma unroll
+        for (int k = 0; k < MIX_KMAX; ++k)
+            if (k < K) gWp_part[(((long long)t * B + b) * M + m) * K + k] = gw[k];
+    }
+}
+
+static int check_mix(const char *fn, int B, int L, int K, int S, int M, int ldw)
+{
+    if (B <= 0 || L <= 0 || K <= 0 || S <= 0 || M <= 0 || ldw < K)
+        return fail(-4, "%s: bad sizes B=%d L=%d K=%d S=%d M=%d ldw=%d", fn, B, L, K, S, M, ldw);
+    if (B > 65535) return fail(-5, "%s: B=%d exceeds the grid y limit", fn, B);
+    return 0;
+}
+
+}  // namespace dmn
+
+using namespace dmn;
+
+extern "C" int dmn_mix_bcast_add(const float *A, const float *Bt, const float *P, const float *Wp,
+                                 int ldw, float *Q, int B, int L, int K, int S, int M, void *stream)
+{
+    if (!A || !Bt || !P || !Wp || !Q) return fail(-1, "dmn_mix_bcast_add: NULL pointer");
+    if (int rc = check_mix("dmn_mix_bcast_add", B, L, K, S, M, ldw)) return rc;
+    const size_t lds = (size_t)L * K * MIX_PT * sizeof(float);
+    if (lds > 64 * 1024) return fail(-5, "dmn_mix_bcast_add: L*K=%d too large for the LDS stage", L * K);
+    dim3 grid((S + MIX_PT - 1) / MIX_PT, B);
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = (M % 4 == 0) && !(((uintptr_t)A | (uintptr_t)Bt | (uintptr_t)Q) & 15);
+    const bool kreg = K <= MIX_KMAX;
+    if (vec && kreg) hipLaunchKernelGGL((mix_fwd_kernel<4, true>), grid, dim3(256), lds, s, A, Bt, P, Wp, ldw, Q, B, L, K, S, M);
+    else if (vec)    hipLaunchKernelGGL((mix_fwd_kernel<4, false>), grid, dim3(256), lds, s, A, Bt, P, Wp, ldw, Q, B, L, K, S, M);
+    else if (kreg)   hipLaunchKernelGGL((mix_fwd_kernel<1, true>), grid, dim3(256), lds, s, A, Bt, P, Wp, ldw, Q, B, L, K, S, M);
+    else             hipLaunchKernelGGL((mix_fwd_kernel<1, false>), grid, dim3(256), lds, s, A, Bt, P, Wp, ldw, Q, B, L, K, S, M);
+    return launch_status("dmn_mix_bcast_add");
+}
+
+extern "C" int dmn_mix_bcast_add_bwd(const float *gQ, const float *P, const float *Wp, int ldw,
+                                     float *gA, float *gBt, float *gP, float *gWp_part, int B,
+                                     int L, int K, int S, int M, void *stream)
+{
+    if (!gQ || !P || !Wp || !gA || !gBt || !gP || !gWp_part)
+        return fail(-1, "dmn_mix_bcast_add_bwd: NULL pointer");
+    if (int rc = check_mix("dmn_mix_bcast_add_bwd", B, L, K, S, M, ldw)) return rc;
+    if (K > MIX_KMAX) return fail(-5, "dmn_mix_bcast_add_bwd: K=%d > %d not supported", K, MIX_KMAX);
+    if (M > 1024) return fail(-5, "dmn_mix_bcast_add_bwd: M=%d > 1024 not supported", M);
+    const size_t lds = (size_t)K * S * sizeof(float);
+    if (lds > 64 * 1024) return fail(-5, "dmn_mix_bcast_add_bwd: K*S=%d too large for the LDS stage", K * S);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(mix_bwd_pix_kernel, dim3(S, B), dim3(256), 0, s, gQ, Wp, ldw, gA, gP, B, L, K, S, M);
+    hipLaunchKernelGGL(mix_bwd_word_kernel, dim3(L, B), dim3(256), lds, s, gQ, P, gBt, gWp_part, B, L, K, S, M);
+    return launch_status("dmn_mix_bcast_add_bwd");
+}

@@ -1,0 +1,169 @@
+# -*- coding: utf-8 -*-
+"""Dual Path Network feature extractor (stays on MIOpen; out of the HIP hot path).
+
+Own definition of the backbone the reference builds with ``create_model('dpn92', 1,
+pretrained=..., extra=...)`` (dmn_pytorch/models/dmn.py:96-98 ->
+dmn_pytorch/models/dpn/dpn_model.py:272-374).  What must match for drop-in use is the
+state_dict (names + shapes, so published DMN checkpoints load) and the five pyramid taps:
+
+* features[0]: the raw 7x7/2 stem convolution BEFORE batch-norm (dpn_model.py:191-197;
+  the reference evaluates that convolution twice, here once -- same values);
+* features[1..4]: cat(residual, dense) after conv2_3 / conv3_4 / conv4_20 / conv5_3
+  (dpn_model.py:358-362); output = conv5_bn_ac of the last block (2688 ch for dpn92).
+
+No torchvision import and no URL download: ``pretrained=True`` raises.
+"""
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+BN_EPS = 1e-3
+
+#          stem  k_r  groups  blocks per stage   dense increment     small  b
+VARIANTS = {
+    "dpn68": (10, 128, 32, (3, 4, 12, 3), (16, 32, 32, 64), True, False),
+    "dpn68b": (10, 128, 32, (3, 4, 12, 3), (16, 32, 32, 64), True, True),
+    "dpn92": (64, 96, 32, (3, 4, 20, 3), (16, 32, 24, 128), False, False),
+    "dpn98": (96, 160, 40, (3, 6, 20, 3), (16, 32, 32, 128), False, False),
+    "dpn131": (128, 160, 40, (4, 8, 28, 3), (16, 32, 32, 128), False, False),
+    "dpn107": (128, 200, 50, (4, 8, 20, 3), (20, 64, 64, 128), False, False),
+}
+
+
+def _join(x):
+    return torch.cat(x, dim=1) if isinstance(x, tuple) else x
+
+
+class CatBnAct(nn.Module):
+    def __init__(self, ch):
+        super().__init__()
+        self.bn = nn.BatchNorm2d(ch, eps=BN_EPS)
+        self.act = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        return self.act(self.bn(_join(x)))
+
+
+class BnActConv2d(nn.Module):
+    def __init__(self, cin, cout, kernel, stride, padding=0, groups=1):
+        super().__init__()
+        self.bn = nn.BatchNorm2d(cin, eps=BN_EPS)
+        self.act = nn.ReLU(inplace=True)
+        self.conv = nn.Conv2d(cin, cout, kernel, stride, padding, groups=groups, bias=False)
+
+    def forward(self, x):
+        return self.conv(self.act(self.bn(x)))
+
+
+class InputBlock(nn.Module):
+    def __init__(self, ch, kernel=7, padding=3):
+        super().__init__()
+        self.conv = nn.Conv2d(3, ch, kernel, stride=2, padding=padding, bias=False)
+        self.bn = nn.BatchNorm2d(ch, eps=BN_EPS)
+        self.act = nn.ReLU(inplace=True)
+        self.pool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+
+    def forward(self, x):
+        raw = self.conv(x)
+        # bn must not run in place on `raw`: it is returned as pyramid level 0
+        return self.pool(self.act(self.bn(raw))), raw
+
+
+class DualPathBlock(nn.Module):
+    """kind: 'proj' (stride 1 projection), 'down' (stride 2 projection) or 'normal'."""
+
+    def __init__(self, cin, c1a, c3b, c1c, inc, groups, kind="normal", b=False):
+        super().__init__()
+        self.c1c, self.inc, self.b = c1c, inc, b
+        self.kind = kind
+        stride = 2 if kind == "down" else 1
+        if kind == "down":
+            self.c1x1_w_s2 = BnActConv2d(cin, c1c + 2 * inc, 1, 2)
+        elif kind == "proj":
+            self.c1x1_w_s1 = BnActConv2d(cin, c1c + 2 * inc, 1, 1)
+        self.c1x1_a = BnActConv2d(cin, c1a, 1, 1)
+        self.c3x3_b = BnActConv2d(c1a, c3b, 3, stride, padding=1, groups=groups)
+        if b:
+            self.c1x1_c = CatBnAct(c3b)
+            self.c1x1_c1 = nn.Conv2d(c3b, c1c, 1, bias=False)
+            self.c1x1_c2 = nn.Conv2d(c3b, inc, 1, bias=False)
+        else:
+            self.c1x1_c = BnActConv2d(c3b, c1c + inc, 1, 1)
+
+    def forward(self, x):
+        xin = _join(x)
+        if self.kind == "normal":
+            res, dense = x
+        else:
+            proj = self.c1x1_w_s2(xin) if self.kind == "down" else self.c1x1_w_s1(xin)
+            res, dense = proj[:, :self.c1c], proj[:, self.c1c:]
+        y = self.c3x3_b(self.c1x1_a(xin))
+        if self.b:
+            y = self.c1x1_c(y)
+            o1, o2 = self.c1x1_c1(y), self.c1x1_c2(y)
+        else:
+            y = self.c1x1_c(y)
+            o1, o2 = y[:, :self.c1c], y[:, self.c1c:]
+        return res + o1, torch.cat([dense, o2], dim=1)
+
+
+class DPN(nn.Module):
+    def __init__(self, variant="dpn92"):
+        super().__init__()
+        stem, k_r, groups, k_sec, inc_sec, small, b = VARIANTS[variant]
+        bw_factor = 1 if small else 4
+        blocks = OrderedDict()
+        blocks["conv1_1"] = InputBlock(stem, 3 if small else 7, 1 if small else 3)
+        cin = stem
+        self.taps = []
+        for stage in range(4):
+            bw = 64 * (2 ** stage) * bw_factor
+            inc = inc_sec[stage]
+            r = (k_r * bw) // (64 * bw_factor)
+            name = "conv%d_" % (stage + 2)
+            blocks[name + "1"] = DualPathBlock(cin, r, r, bw, inc, groups,
+                                               "proj" if stage == 0 else "down", b)
+            cin = bw + 3 * inc
+            for i in range(2, k_sec[stage] + 1):
+                blocks[name + str(i)] = DualPathBlock(cin, r, r, bw, inc, groups, "normal", b)
+                cin += inc
+            self.taps.append(name + str(k_sec[stage]))
+        blocks["conv5_bn_ac"] = CatBnAct(cin)
+        self.out_channels = cin
+        self.features = nn.Sequential(blocks)
+
+    def forward(self, x):
+        feats = []
+        out = x
+        for name, module in self.features.named_children():
+            if name == "conv1_1":
+                out, raw = module(out)
+                feats.append(raw)
+            else:
+                out = module(out)
+                if name in self.taps:
+                    feats.append(_join(out))
+        return out, feats
+
+    def load_state_dict(self, new_state, strict=False):
+        """Lenient by name, like dpn_model.py:376-381."""
+        state = self.state_dict()
+        for key in state:
+            if key in new_state:
+                state[key] = new_state[key]
+        return super().load_state_dict(state)
+
+
+def create_backbone(name, pretrained=False, extra=True):
+    if name not in VARIANTS:
+        raise NotImplementedError(
+            "dms_amd: backbone %r is not available (only DPN variants %s; the torchvision "
+            "backbones of the reference's model_factory are outside the DMN path)"
+            % (name, sorted(VARIANTS)))
+    if pretrained:
+        raise RuntimeError(
+            "dms_amd: pretrained=True would download ImageNet weights "
+            "(dpn_model.py:37-54,103-104); construct with pretrained=False and load a "
+            "state_dict instead")
+    return DPN(name)

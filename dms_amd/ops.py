@@ -1,0 +1,249 @@
+# -*- coding: utf-8 -*-
+"""Torch-facing wrappers of the HIP entry points (include/dmn_hip.h).
+
+PyTorch is plumbing here: it owns device memory, streams and autograd bookkeeping; every
+operator below runs in libdmn_hip.so.  Tensors must be fp32 and on a ROCm device --
+anything else raises (there is no CPU or eager fallback).
+"""
+import torch
+
+from . import _lib
+
+ACT_IDS = {"identity": 0, "tanh": 1, "relu": 2}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(name, t, shape=None):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise RuntimeError("dms_amd.%s: tensor is on %s; the HIP path needs a ROCm device "
+                           "(no CPU fallback exists)" % (name, t.device))
+    if t.dtype != torch.float32:
+        raise RuntimeError("dms_amd.%s: expected float32, got %s" % (name, t.dtype))
+    if not t.is_contiguous():
+        raise RuntimeError("dms_amd.%s: tensor must be contiguous" % name)
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise RuntimeError("dms_amd.%s: expected shape %s, got %s" % (name, tuple(shape), tuple(t.shape)))
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+# ------------------------------------------------------------------------------------
+# SRU scan
+# ------------------------------------------------------------------------------------
+def sru_scan_chunks(T, ncols):
+    """How many time chunks the time-parallel variant should use (1 = plain column scan)."""
+    waves = (ncols + 63) // 64
+    if waves >= 512 or T < 512:
+        return 1
+    n = min(max(2048 // waves, 1), T // 64)
+    return max(n, 1)
+
+
+def sru_forward_raw(u, x, bias, c0, act, scale_x, h_t0=0, want_c=False, nchunks=None):
+    """u (T,B,d,k); x (T,B,d) or None; returns h (T-h_t0,B,d), c_all|None, c_last (B,d)."""
+    T, B, d, k = u.shape
+    _chk("sru_fwd", u)
+    _chk("sru_fwd", x, (T, B, d) if x is not None else None)
+    _chk("sru_fwd", bias, (2 * d,))
+    _chk("sru_fwd", c0, (B, d) if c0 is not None else None)
+    with torch.cuda.device(u.device):
+        h = torch.empty((T - h_t0, B, d), device=u.device, dtype=torch.float32)
+        c_last = torch.empty((B, d), device=u.device, dtype=torch.float32)
+        c_all = torch.empty((T, B, d), device=u.device, dtype=torch.float32) if want_c else None
+        if nchunks is None:
+            nchunks = 1 if want_c else sru_scan_chunks(T, B * d)
+        if nchunks > 1 and not want_c:
+            ws = torch.empty(2 * nchunks * B * d, device=u.device, dtype=torch.float32)
+            _lib.call("dmn_sru_fwd_scan", _ptr(u), _ptr(x), _ptr(bias), _ptr(c0), _ptr(h),
+                      _ptr(c_last), _ptr(ws), T, B, d, k, ACT_IDS[act], float(scale_x),
+                      int(h_t0), int(nchunks), _stream())
+        else:
+            _lib.call("dmn_sru_fwd", _ptr(u), _ptr(x), _ptr(bias), _ptr(c0), _ptr(h),
+                      _ptr(c_all), _ptr(c_last), T, B, d, k, ACT_IDS[act], float(scale_x),
+                      int(h_t0), _stream())
+    return h, c_all, c_last
+
+
+class _SRUCompute(torch.autograd.Function):
+    """Autograd node of the scan (the role of upstream's SRU_Compute)."""
+
+    @staticmethod
+    def forward(ctx, u, x, bias, c0, act, scale_x):
+        h, c_all, c_last = sru_forward_raw(u, x, bias, c0, act, scale_x, 0, want_c=True)
+        ctx.save_for_backward(u, x, bias, c0, c_all)
+        ctx.act, ctx.scale_x = act, scale_x
+        return h, c_last
+
+    @staticmethod
+    def backward(ctx, grad_h, grad_last):
+        u, x, bias, c0, c_all = ctx.saved_tensors
+        T, B, d, k = u.shape
+        grad_h = grad_h.contiguous()
+        grad_last = grad_last.contiguous() if grad_last is not None else None
+        with torch.cuda.device(u.device):
+            gu = torch.empty_like(u)
+            gx = torch.empty((T, B, d), device=u.device, dtype=torch.float32) if k == 3 else None
+            gbp = torch.empty((2, B, d), device=u.device, dtype=torch.float32)
+            gc0 = torch.empty((B, d), device=u.device, dtype=torch.float32)
+            _lib.call("dmn_sru_bwd", _ptr(u), _ptr(x), _ptr(bias), _ptr(c0), _ptr(c_all),
+                      _ptr(grad_h), _ptr(grad_last), _ptr(gu), _ptr(gx), _ptr(gbp), _ptr(gc0),
+                      T, B, d, k, ACT_IDS[ctx.act], float(ctx.scale_x), _stream())
+        gbias = gbp.sum(dim=1).reshape(2 * d)
+        return gu, gx, gbias, (gc0 if c0 is not None else None), None, None
+
+
+def sru_compute(u, x, bias, c0=None, act="tanh", scale_x=1.0, h_t0=0):
+    """h, c_last = scan(u, x).  With autograd: full h is produced, then sliced."""
+    needs_grad = torch.is_grad_enabled() and any(
+        t is not None and t.requires_grad for t in (u, x, bias, c0))
+    if needs_grad:
+        h, c_last = _SRUCompute.apply(u, x, bias, c0, act, scale_x)
+        return (h[h_t0:] if h_t0 else h), c_last
+    h, _, c_last = sru_forward_raw(u, x, bias, c0, act, scale_x, h_t0, want_c=False)
+    return h, c_last
+
+
+# ------------------------------------------------------------------------------------
+# coordinate channels + concat
+# ------------------------------------------------------------------------------------
+class _CatCoords(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vis):
+        B, C, H, W = vis.shape
+        _chk("cat_coords", vis)
+        with torch.cuda.device(vis.device):
+            V = torch.empty((B, C + 8, H, W), device=vis.device, dtype=torch.float32)
+            _lib.call("dmn_cat_coords", _ptr(vis), _ptr(V), B, C, H, W, _stream())
+        ctx.C = C
+        return V
+
+    @staticmethod
+    def backward(ctx, gV):
+        return gV[:, :ctx.C].contiguous()
+
+
+def cat_coords(vis):
+    return _CatCoords.apply(vis.contiguous())
+
+
+# ------------------------------------------------------------------------------------
+# dynamic filters
+# ------------------------------------------------------------------------------------
+class _DynFilter(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, V, F):
+        B, C, S = V.shape
+        L, B2, K, C2 = F.shape
+        if B2 != B or C2 != C:
+            raise RuntimeError("dms_amd.dynfilter: V %s vs F %s" % (tuple(V.shape), tuple(F.shape)))
+        _chk("dynfilter", V)
+        _chk("dynfilter", F)
+        with torch.cuda.device(V.device):
+            P = torch.empty((L, B, K, S), device=V.device, dtype=torch.float32)
+            _lib.call("dmn_dynfilter_fwd", _ptr(V), _ptr(F), _ptr(P), B, L, K, C, S, _stream())
+        ctx.save_for_backward(V, F)
+        return P
+
+    @staticmethod
+    def backward(ctx, gP):
+        V, F = ctx.saved_tensors
+        B, C, S = V.shape
+        L, _, K, _ = F.shape
+        gP = gP.contiguous()
+        with torch.cuda.device(V.device):
+            gV = torch.empty_like(V) if ctx.needs_input_grad[0] else None
+            gF = torch.empty_like(F) if ctx.needs_input_grad[1] else None
+            _lib.call("dmn_dynfilter_bwd", _ptr(V), _ptr(F), _ptr(gP), _ptr(gV), _ptr(gF),
+                      B, L, K, C, S, _stream())
+        return gV, gF
+
+
+def dynfilter(V, F):
+    """V (B,C,S), F (L,B,K,C) -> P (L,B,K,S);  P[t,b,k,s] = sum_c F[t,b,k,c] V[b,c,s]."""
+    return _DynFilter.apply(V.contiguous(), F.contiguous())
+
+
+# ------------------------------------------------------------------------------------
+# concat-free mix
+# ------------------------------------------------------------------------------------
+class _MixBcastAdd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, A, Bt, P, Wp):
+        B, S, M = A.shape
+        L, _, K, _ = P.shape
+        _chk("mix", A)
+        _chk("mix", Bt, (L, B, M))
+        _chk("mix", P, (L, B, K, S))
+        if not (Wp.is_cuda and Wp.dtype == torch.float32 and tuple(Wp.shape) == (M, K)
+                and Wp.stride(1) == 1):
+            raise RuntimeError("dms_amd.mix: Wp must be a cuda float32 (M,K) view with unit inner stride")
+        ldw = Wp.stride(0)
+        with torch.cuda.device(A.device):
+            Q = torch.empty((S * L, B, M), device=A.device, dtype=torch.float32)
+            _lib.call("dmn_mix_bcast_add", _ptr(A), _ptr(Bt), _ptr(P), _ptr(Wp), ldw, _ptr(Q),
+                      B, L, K, S, M, _stream())
+        ctx.save_for_backward(P, Wp)
+        return Q
+
+    @staticmethod
+    def backward(ctx, gQ):
+        P, Wp = ctx.saved_tensors
+        L, B, K, S = P.shape
+        M = Wp.shape[0]
+        gQ = gQ.contiguous()
+        dev = gQ.device
+        with torch.cuda.device(dev):
+            gA = torch.empty((B, S, M), device=dev, dtype=torch.float32)
+            gBt = torch.empty((L, B, M), device=dev, dtype=torch.float32)
+            gP = torch.empty((L, B, K, S), device=dev, dtype=torch.float32)
+            gWpp = torch.empty((L, B, M, K), device=dev, dtype=torch.float32)
+            _lib.call("dmn_mix_bcast_add_bwd", _ptr(gQ), _ptr(P), _ptr(Wp), Wp.stride(0),
+                      _ptr(gA), _ptr(gBt), _ptr(gP), _ptr(gWpp), B, L, K, S, M, _stream())
+        return gA, gBt, gP, gWpp.sum(dim=(0, 1))
+
+
+def mix_bcast_add(A, Bt, P, Wp):
+    """Q[(s*L+t), b, m] = A[b,s,m] + Bt[t,b,m] + sum_k Wp[m,k] P[t,b,k,s] -> (S*L, B, M)."""
+    return _MixBcastAdd.apply(A.contiguous(), Bt.contiguous(), P.contiguous(), Wp)
+
+
+# ------------------------------------------------------------------------------------
+# cat + bilinear x2
+# ------------------------------------------------------------------------------------
+class _CatUpsample2x(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, feat):
+        B, Cx, H, W = x.shape
+        B2, Cf, H2, W2 = feat.shape
+        if (B2, H2, W2) != (B, H, W):
+            raise RuntimeError("dms_amd.cat_upsample2x: x %s vs feat %s" % (tuple(x.shape), tuple(feat.shape)))
+        _chk("cat_upsample2x", x)
+        _chk("cat_upsample2x", feat)
+        with torch.cuda.device(x.device):
+            out = torch.empty((B, Cx + Cf, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
+            _lib.call("dmn_cat_upsample2x", _ptr(x), _ptr(feat), _ptr(out), B, Cx, Cf, H, W, _stream())
+        ctx.dims = (B, Cx, Cf, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, Cx, Cf, H, W = ctx.dims
+        g = g.contiguous()
+        with torch.cuda.device(g.device):
+            gx = torch.empty((B, Cx, H, W), device=g.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+            gf = torch.empty((B, Cf, H, W), device=g.device, dtype=torch.float32) if ctx.needs_input_grad[1] else None
+            if gx is not None or gf is not None:
+                _lib.call("dmn_cat_upsample2x_bwd", _ptr(g), _ptr(gx), _ptr(gf), B, Cx, Cf, H, W, _stream())
+        return gx, gf
+
+
+def cat_upsample2x(x, feat):
+    """bilinear x2 (align_corners=False) of cat([x, feat], 1), one pass."""
+    return _CatUpsample2x.apply(x.contiguous(), feat.contiguous())

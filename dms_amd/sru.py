@@ -1,0 +1,89 @@
+# -*- coding: utf-8 -*-
+"""SRU modules backed by the HIP scan kernels (drop-in for ``from sru import SRU``).
+
+The reference builds its language encoder and its multimodal RNN with the third-party
+package ``sru`` (dmn_pytorch/models/dmn.py:7,104,120) and calls ``h, c = rnn(x)`` with
+``x (len, B, n_in)`` (dmn.py:156,204).  This module keeps that surface -- constructor
+``SRU(input_size, hidden_size, num_layers=2, ...)``, ``forward(input, c0=None)`` returning
+``(h (len,B,hidden), c (num_layers,B,hidden))``, parameters ``rnn_lst.{i}.weight
+(n_in, hidden*k)`` (k innermost; k = 3 when n_in == hidden else 4) and ``rnn_lst.{i}.bias
+(2*hidden)`` = [forget | reset] -- and replaces the cupy/pynvrtc CUDA kernel by
+libdmn_hip.so.  The x.W projection stays a library GEMM (rocBLAS/hipBLASLt via torch).
+
+Not implemented (unused by the reference, which constructs SRU with defaults only):
+dropout / rnn_dropout, bidirectional, layer/weight norm.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class SRUCell(nn.Module):
+    def __init__(self, n_in, n_out, use_tanh=1, use_relu=0, scale_x=1.0):
+        super().__init__()
+        self.n_in, self.n_out = n_in, n_out
+        self.k = 4 if n_in != n_out else 3
+        self.activation = "relu" if use_relu else ("tanh" if use_tanh else "identity")
+        self.scale_x = float(scale_x)
+        self.weight = nn.Parameter(torch.empty(n_in, n_out * self.k))
+        self.bias = nn.Parameter(torch.empty(n_out * 2))
+        self.init_weight()
+
+    def init_weight(self):
+        val = math.sqrt(3.0 / self.n_in)
+        with torch.no_grad():
+            self.weight.uniform_(-val, val)
+            self.bias.zero_()
+
+    def set_bias(self, bias_val=0.0):
+        with torch.no_grad():
+            self.bias[self.n_out:].fill_(bias_val)
+
+    def forward(self, input, c0=None, h_t0=0):
+        if input.dim() != 3:
+            raise ValueError("SRUCell expects (len, batch, n_in), got %s" % (tuple(input.shape),))
+        T, B, n_in = input.shape
+        if n_in != self.n_in:
+            raise ValueError("SRUCell: input width %d != n_in %d" % (n_in, self.n_in))
+        x = input.contiguous()
+        u = x.view(T * B, n_in).mm(self.weight).view(T, B, self.n_out, self.k)
+        return ops.sru_compute(u, x if self.k == 3 else None, self.bias, c0,
+                               self.activation, self.scale_x, h_t0)
+
+
+class SRU(nn.Module):
+    def __init__(self, input_size, hidden_size, num_layers=2, dropout=0, rnn_dropout=0,
+                 bidirectional=False, use_tanh=1, use_relu=0, scale_x=1.0):
+        super().__init__()
+        if dropout or rnn_dropout or bidirectional:
+            raise NotImplementedError(
+                "dms_amd.SRU: dropout / bidirectional are not on the DMN path (dmn.py:104,120 "
+                "construct SRU with defaults) and are not implemented")
+        self.n_in, self.n_out, self.depth = input_size, hidden_size, num_layers
+        self.rnn_lst = nn.ModuleList([
+            SRUCell(input_size if i == 0 else hidden_size, hidden_size, use_tanh, use_relu, scale_x)
+            for i in range(num_layers)])
+
+    def set_bias(self, bias_val=0.0):
+        for cell in self.rnn_lst:
+            cell.set_bias(bias_val)
+
+    def forward(self, input, c0=None, return_hidden=True, tail=None):
+        """``tail=n`` (extension): only the last n steps of the LAST layer's h are produced
+        (what dmn.py:209 keeps), so the final scan stores S instead of S*L rows."""
+        if input.dim() != 3:
+            raise ValueError("SRU expects (len, batch, n_in), got %s" % (tuple(input.shape),))
+        T = input.shape[0]
+        c0s = [None] * self.depth if c0 is None else [c.contiguous() for c in c0.unbind(0)]
+        prev, lst = input, []
+        for i, cell in enumerate(self.rnn_lst):
+            last = i == self.depth - 1
+            h_t0 = max(T - int(tail), 0) if (last and tail is not None) else 0
+            prev, c = cell(prev, c0s[i], h_t0)
+            lst.append(c)
+        if return_hidden:
+            return prev, torch.stack(lst)
+        return prev

@@ -1,0 +1,144 @@
+/*
+ * include/dmn_hip.h -- C ABI of libdmn_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the DMN language-conditioned hot path of BCV-Uniandes/DMS
+ * (reference: dmn_pytorch/models/dmn.py).  Every entry point is `extern "C"`, takes
+ * plain device pointers + sizes, and replaces the reference interface cited above it.
+ *
+ * Conventions (all entry points)
+ *   - All tensors are fp32, contiguous, row-major, resident in device memory and OWNED
+ *     BY THE CALLER; the library never allocates, frees or retains them.
+ *   - `stream` is a hipStream_t (NULL = default stream).  Calls are asynchronous on it;
+ *     nothing inside synchronises the device.  The caller's current device is used.
+ *   - Return value: 0 = ok; < 0 = rejected argument (nothing launched);
+ *     > 0 = hipError_t from the launch.  dmn_last_error() gives the message of the last
+ *     failure on the calling thread.  No C++ exception crosses the boundary.
+ *   - Re-entrant, no global mutable state besides the thread-local error string.
+ */
+#ifndef DMN_HIP_H
+#define DMN_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DMN_ABI_VERSION 1
+
+/* activation ids of the SRU cell (upstream `use_tanh` / `use_relu` switches) */
+#define DMN_ACT_IDENTITY 0
+#define DMN_ACT_TANH     1
+#define DMN_ACT_RELU     2
+
+int dmn_abi_version(void);
+const char *dmn_last_error(void);
+
+/*
+ * SRU forward scan.  Replaces the third-party `sru` package's `SRU_Compute.forward`
+ * -> cupy/pynvrtc kernel `sru_fwd`, reached from dmn.py:104,120 (construction) and
+ * dmn.py:156,204 (`h, c = rnn(x)`).
+ *   U     (T, B, d, k)  k innermost, k in {3,4}: U = x . W done by the caller (GEMM)
+ *   x     (T, B, d)     highway input when k == 3; must be NULL when k == 4
+ *   bias  (2*d)         [forget | reset]
+ *   c0    (B, d)        or NULL (= zeros, what dmn.py does)
+ *   h     (T - h_t0, B, d)  hidden states of steps t >= h_t0 (h_t0 = 0: all steps).
+ *                       dmn.py:209 keeps only the last H*W steps of the mSRU, so the
+ *                       last layer is called with h_t0 = T - H*W.
+ *   c_all (T, B, d)     or NULL (inference: per-step cell states are not stored)
+ *   c_last(B, d)        or NULL
+ */
+int dmn_sru_fwd(const float *U, const float *x, const float *bias, const float *c0,
+                float *h, float *c_all, float *c_last,
+                int T, int B, int d, int k, int act, float scale_x, int h_t0,
+                void *stream);
+
+/*
+ * Same operation and reference interface as dmn_sru_fwd (dmn.py:156,204), time-parallel:
+ * for FEW columns (B*d small, e.g. batch-1 serving: 1005 columns = 16 wavefronts) the
+ * sequence is cut into `nchunks` chunks that run concurrently -- the cell update is the
+ * affine map c -> f*c + (1-f)*u0, so chunk aggregates (A, Bv) compose associatively.
+ * Inference only (no c_all).  `workspace` holds dmn_sru_scan_workspace_floats(...) floats
+ * (2 * nchunks * B * d), caller-owned, 8-byte aligned.
+ */
+int dmn_sru_scan_workspace_floats(int T, int B, int d, int nchunks);
+int dmn_sru_fwd_scan(const float *U, const float *x, const float *bias, const float *c0,
+                     float *h, float *c_last, float *workspace,
+                     int T, int B, int d, int k, int act, float scale_x, int h_t0,
+                     int nchunks, void *stream);
+
+/*
+ * SRU backward scan (reverse time). Replaces `SRU_Compute.backward` -> `sru_bwd`
+ * of the same package (autograd of dmn.py:156,204).
+ *   c_all (T,B,d) saved by the forward; grad_h (T,B,d); grad_last (B,d) or NULL.
+ *   grad_U (T,B,d,k); grad_x (T,B,d) iff k == 3 else NULL;
+ *   grad_bias_part (2, B, d): per-(batch, column) partial sums, caller reduces over B;
+ *   grad_c0 (B, d).
+ */
+int dmn_sru_bwd(const float *U, const float *x, const float *bias, const float *c0,
+                const float *c_all, const float *grad_h, const float *grad_last,
+                float *grad_U, float *grad_x, float *grad_bias_part, float *grad_c0,
+                int T, int B, int d, int k, int act, float scale_x, void *stream);
+
+/*
+ * Coordinate channels + concat.  Replaces BaseDMN.generate_spatial_batch
+ * (dmn.py:225-246: host double loop + H2D copy every forward) and
+ * torch.cat([vis, spatial], 1) (dmn.py:142).
+ *   vis (B, C, H, W) -> V (B, C + 8, H, W), V[:, C:C+8] = [xmin,ymin,xmax,ymax,xctr,yctr,1/W,1/H]
+ */
+int dmn_cat_coords(const float *vis, float *V, int B, int C, int H, int W, void *stream);
+
+/*
+ * Dynamic filters.  Replaces `for t: F.conv2d(vis, filters[t])` + torch.cat
+ * (dmn.py:178-184) by one batched thin GEMM:
+ *   P[t,b,k,s] = sum_c F[t,b,k,c] * V[b,c,s]
+ *   V (B, C, S)   F (L, B, K, C)   P (L, B, K, S)
+ */
+int dmn_dynfilter_fwd(const float *V, const float *F, float *P,
+                      int B, int L, int K, int C, int S, void *stream);
+
+/* gradients of the above: gF (L,B,K,C) = gP . V^T ; gV (B,C,S) = sum_{t,k} F * gP */
+int dmn_dynfilter_bwd(const float *V, const float *F, const float *gP,
+                      float *gV, float *gF,
+                      int B, int L, int K, int C, int S, void *stream);
+
+/*
+ * Concat-free mix.  Replaces expand + torch.cat([vis, lang_mix, p], 2) (dmn.py:152-161,
+ * 170,187-189), the 1x1 comb_conv (dmn.py:192) and the view/permute/contiguous into the
+ * mSRU sequence order n = s*L + t (dmn.py:196-201).  With comb_conv.weight split by
+ * channel block [vis+coords | WE | h | P] the caller supplies two small GEMM results:
+ *   A  (B, S, M)  = V[b]^T . Wv^T            (vis + coordinate channels)
+ *   Bt (L, B, M)  = [WE_t ; h_t] . Wl^T + bias
+ *   P  (L, B, K, S), Wp (M, K) with row stride ldw (a column slice of comb_conv.weight)
+ * and this kernel writes
+ *   Q[(s*L + t), b, m] = A[b,s,m] + Bt[t,b,m] + sum_k Wp[m,k] * P[t,b,k,s]      (S*L, B, M)
+ */
+int dmn_mix_bcast_add(const float *A, const float *Bt, const float *P, const float *Wp,
+                      int ldw, float *Q, int B, int L, int K, int S, int M, void *stream);
+
+/*
+ * gradients of dmn_mix_bcast_add w.r.t. A, Bt, P, Wp given gQ (S*L, B, M):
+ *   gA[b,s,m] = sum_t gQ ; gBt[t,b,m] = sum_s gQ ; gP[t,b,k,s] = sum_m Wp[m,k] gQ ;
+ *   gWp_part (L, B, M, K) partial sums per (word, batch entry) (caller reduces over L, B).
+ *   Limits: K <= 16, M <= 1024.
+ */
+int dmn_mix_bcast_add_bwd(const float *gQ, const float *P, const float *Wp, int ldw,
+                          float *gA, float *gBt, float *gP, float *gWp_part,
+                          int B, int L, int K, int S, int M, void *stream);
+
+/*
+ * Upsampling glue.  Replaces torch.cat([x, features[i]], 1) followed by
+ * nn.Upsample(scale_factor=2, mode='bilinear') (align_corners=False) in
+ * UpsamplingModule.forward (dmn.py:324,337-338); the 3x3 convolution that follows
+ * stays on MIOpen.
+ *   x (B, Cx, H, W), feat (B, Cf, H, W) -> out (B, Cx + Cf, 2H, 2W)
+ */
+int dmn_cat_upsample2x(const float *x, const float *feat, float *out,
+                       int B, int Cx, int Cf, int H, int W, void *stream);
+
+/* gradient of the above: g (B, Cx+Cf, 2H, 2W) -> gx (B,Cx,H,W), gfeat (B,Cf,H,W) (either may be NULL) */
+int dmn_cat_upsample2x_bwd(const float *g, float *gx, float *gfeat,
+                           int B, int Cx, int Cf, int H, int W, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMN_HIP_H */

@@ -1,0 +1,193 @@
+# -*- coding: utf-8 -*-
+"""oracle/gen_golden.py -- TEST INFRASTRUCTURE ONLY; run ONCE in the build container.
+
+    python -B oracle/gen_golden.py            # writes tests/golden/*.npz
+
+Imports the reference's own ``dmn_pytorch/models/dmn.py`` from /root/reference (which
+does not travel to the GPU box) and records its outputs on deterministic inputs
+(oracle/detgen.py), so tests can pin oracle/dmn_ref.py -- and, through it, the HIP
+path -- against what the reference itself computes.  Only data (inputs are rebuilt
+from seeds; outputs are stored) lands in tests/golden/.
+
+What is / is not reference code in those vectors:
+* dmn.py's glue (BaseDMN.forward, UpsamplingModule.forward, DMN.forward,
+  generate_spatial_batch) and the DPN92 definition run UNMODIFIED.
+* The third-party `sru` package is absent (README.md:33), so ``sru.SRU`` is bound to
+  oracle/sru_ref.SRURef -- the SRU arithmetic in these vectors is OUR restatement
+  ("parity unpinned" for that part).
+* Modules that dmn.py's import chain pulls in at import time but the dpn92 path never
+  calls (torchvision.*) are bound to empty placeholder modules.
+* ``Tensor.cuda`` is made a no-op for the hard-coded ``.cuda()`` at dmn.py:246.
+"""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+from oracle import sru_ref                              # noqa: E402
+from oracle.detgen import det_uniform, det_ints, det_fill_state   # noqa: E402
+
+
+def import_reference():
+    """Load dmn_pytorch.models.dmn without running dmn_pytorch/__init__.py
+    (which would import the dataset loader -> cv2 / referit)."""
+    sru_mod = types.ModuleType("sru")
+    sru_mod.SRU = sru_ref.SRURef
+    sys.modules["sru"] = sru_mod
+    for name in ["torchvision", "torchvision.models", "torchvision.models.resnet",
+                 "torchvision.models.densenet", "torchvision.models.inception",
+                 "torchvision.models.vgg", "torchvision.transforms"]:
+        m = types.ModuleType(name)
+        m.__path__ = []
+        sys.modules[name] = m
+    for name, attrs in [("torchvision.models.resnet", ["resnet18", "resnet34", "resnet50",
+                                                       "resnet101", "resnet152"]),
+                        ("torchvision.models.densenet", ["densenet121", "densenet169",
+                                                         "densenet161", "densenet201"]),
+                        ("torchvision.models.inception", ["inception_v3"]),
+                        ("torchvision.models.vgg", ["vgg16"])]:
+        for a in attrs:
+            setattr(sys.modules[name], a, None)
+    pkg = types.ModuleType("dmn_pytorch")
+    pkg.__path__ = [os.path.join(REF, "dmn_pytorch")]
+    sys.modules["dmn_pytorch"] = pkg
+    sys.dont_write_bytecode = True
+    torch.Tensor.cuda = lambda self, *a, **k: self      # dmn.py:246
+    return importlib.import_module("dmn_pytorch.models.dmn")
+
+
+class FixedBackbone(nn.Module):
+    """Stands where the DPN goes: returns pre-set (vis, features)."""
+
+    def __init__(self, vis, feats):
+        super().__init__()
+        self.vis, self.feats = vis, feats
+
+    def forward(self, x):
+        return self.vis, list(self.feats)
+
+
+def run_base(dmn, cfg, H, W, L, dict_size, tag, extra=None):
+    vis = det_uniform((1, cfg["vis_size"], H, W), 101, 1.0).clamp_(min=0)   # post-ReLU like
+    lang = det_ints((1, L), 202, dict_size)
+    saved = dmn.create_model
+    dmn.create_model = lambda *a, **k: FixedBackbone(vis, [])
+    try:
+        net = dmn.BaseDMN(dict_size, emb_size=cfg["emb_size"], hid_size=cfg["hid_size"],
+                          vis_size=cfg["vis_size"], num_filters=cfg["num_filters"],
+                          mixed_size=cfg["mixed_size"], hid_mixed_size=cfg["hid_mixed_size"],
+                          lang_layers=cfg["lang_layers"], mixed_layers=cfg["mixed_layers"],
+                          backend="dpn92", mix_we=cfg["mix_we"], pretrained=False,
+                          high_res=cfg["high_res"])
+    finally:
+        dmn.create_model = saved
+    net.eval()
+    state = det_fill_state(net.state_dict())
+    nn.Module.load_state_dict(net, state)
+    with torch.no_grad():
+        out, _ = net(torch.zeros(1, 3, H * 32, W * 32), lang)
+    rec = {"out": out.numpy(), "H": H, "W": W, "L": L, "dict_size": dict_size,
+           "keys": np.array(sorted(state.keys())),
+           "shapes": np.array([str(tuple(state[k].shape)) for k in sorted(state.keys())])}
+    for k, v in cfg.items():
+        rec["cfg_" + k] = v
+    if extra:
+        rec.update(extra)
+    np.savez_compressed(os.path.join(OUT, tag + ".npz"), **rec)
+    print(tag, "out", tuple(out.shape), float(out.abs().mean()), float(out.std()))
+    return net
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    dmn = import_reference()
+
+    # (4) coordinate maps, dmn.py:225-246
+    rec = {}
+    for (H, W) in [(10, 10), (16, 16), (16, 12), (1, 1), (3, 5)]:
+        rec["s_%d_%d" % (H, W)] = dmn.BaseDMN.generate_spatial_batch(H, W).numpy()
+    np.savez_compressed(os.path.join(OUT, "spatial.npz"), **rec)
+
+    # (1) tiny-dims BaseDMN: k=3 everywhere (hid_mixed == mixed) and k=4 first layer
+    tiny = dict(emb_size=16, hid_size=16, vis_size=32, num_filters=3, mixed_size=16,
+                hid_mixed_size=16, lang_layers=2, mixed_layers=3, mix_we=True, high_res=False)
+    run_base(dmn, tiny, 4, 3, 5, 50, "base_tiny_k3")
+    run_base(dmn, dict(tiny, hid_mixed_size=21), 4, 3, 5, 50, "base_tiny_k4")
+    run_base(dmn, dict(tiny, hid_mixed_size=21, mix_we=False, high_res=True, lang_layers=3),
+             3, 4, 7, 50, "base_tiny_k4_nowe_hr")
+
+    # (2) full-dims hot path (config 1's shapes after the backbone: 320px -> 10x10)
+    full = dict(emb_size=1000, hid_size=1000, vis_size=2688, num_filters=10, mixed_size=1000,
+                hid_mixed_size=1005, lang_layers=3, mixed_layers=3, mix_we=True, high_res=False)
+    run_base(dmn, full, 10, 10, 20, 1000, "base_full_320_lowres")
+    run_base(dmn, dict(full, high_res=True), 16, 16, 20, 1000, "base_full_512_highres_feat")
+
+    # (5) UpsamplingModule: small channel counts, all five x2 levels; and one level with
+    # a size mismatch that triggers the resize branch (dmn.py:332-336)
+    fch = [6, 5, 4, 3, 2]
+    up = dmn.UpsamplingModule(7, mode="bilinear", ker_size=3, amplification=8,
+                              feature_channels=fch)
+    up.eval()
+    st = det_fill_state(up.state_dict())
+    up.load_state_dict(st)
+    x = det_uniform((1, 7, 3, 4), 303, 1.0)
+    feats = [None, None,
+             det_uniform((1, fch[2], 12, 16), 306, 1.0),
+             det_uniform((1, fch[1], 6, 8), 305, 1.0),
+             det_uniform((1, fch[0], 3, 4), 304, 1.0)]
+    with torch.no_grad():
+        y = up(x, feats)
+    feats_mis = [None, None,
+                 det_uniform((1, fch[2], 13, 15), 309, 1.0),
+                 det_uniform((1, fch[1], 7, 9), 308, 1.0),
+                 det_uniform((1, fch[0], 4, 5), 307, 1.0)]
+    with torch.no_grad():
+        y2 = up(x, feats_mis)
+    np.savez_compressed(os.path.join(OUT, "upsample_small.npz"), out=y.numpy(), out_mis=y2.numpy(),
+                        keys=np.array(sorted(st.keys())),
+                        shapes=np.array([str(tuple(st[k].shape)) for k in sorted(st.keys())]))
+    print("upsample_small", tuple(y.shape), tuple(y2.shape), float(y.std()))
+
+    # (6) whole reference DMN incl. its own DPN92, 64px image (2x2 feature map), high-res:
+    # pins state_dict keys/shapes of the real model and an end-to-end output
+    torch.manual_seed(1111)
+    net = dmn.DMN(100, num_filters=10, lang_layers=3, mix_we=True, pretrained=False,
+                  high_res=True, upsampling_mode="bilinear", upsampling_amplification=32)
+    net.eval()
+    sd = net.state_dict()
+    keys = sorted(sd.keys())
+    np.savez_compressed(os.path.join(OUT, "dmn_state_keys_highres.npz"),
+                        keys=np.array(keys),
+                        shapes=np.array([str(tuple(sd[k].shape)) for k in keys]))
+    net_lo = dmn.DMN(100, num_filters=10, lang_layers=3, mix_we=True, pretrained=False,
+                     high_res=False)
+    sdl = net_lo.state_dict()
+    keys = sorted(sdl.keys())
+    np.savez_compressed(os.path.join(OUT, "dmn_state_keys_lowres.npz"),
+                        keys=np.array(keys),
+                        shapes=np.array([str(tuple(sdl[k].shape)) for k in keys]))
+    st = det_fill_state(sd)
+    nn.Module.load_state_dict(net, st)
+    img = det_uniform((1, 3, 64, 64), 404, 1.0)
+    words = det_ints((1, 6), 405, 100)
+    with torch.no_grad():
+        y = net(img, words)
+        vis, feats = net.langvis.base(img)
+    np.savez_compressed(os.path.join(OUT, "dmn_e2e_64px_highres.npz"), out=y.numpy(),
+                        vis=vis.numpy(), feat0=feats[0].numpy()[:, :, ::4, ::4],
+                        feat3=feats[3].numpy())
+    print("dmn_e2e_64px_highres", tuple(y.shape), float(y.std()), len(sd))
+
+
+if __name__ == "__main__":
+    main()

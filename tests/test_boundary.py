@@ -1,0 +1,128 @@
+"""CPU tests (-m "not gpu"): the C-ABI library loads and exports every declared symbol,
+the module API mirrors the reference, and the product never reaches into oracle/."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import dms_amd
+from dms_amd import _lib
+from tests.util import load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "dmn_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dmn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    syms = _declared_symbols()
+    assert len(syms) >= 13
+    for s in syms:
+        assert hasattr(lib, s), "libdmn_hip.so does not export %s" % s
+    lib.dmn_abi_version.restype = ctypes.c_int
+    assert lib.dmn_abi_version() == _lib.ABI_VERSION
+    # python-side signature table covers the header (minus the two no-arg helpers)
+    assert set(_lib.SIGNATURES) | {"dmn_abi_version", "dmn_last_error"} == set(syms)
+
+
+def test_bad_arguments_are_rejected_without_a_gpu():
+    lib = _lib.load()
+    # k = 5 is rejected before anything is launched (no device needed)
+    rc = lib.dmn_sru_fwd(1, None, 1, None, 1, None, None, 4, 1, 8, 5, 1, 1.0, 0, None)
+    assert rc < 0
+    assert b"k must be 3 or 4" in lib.dmn_last_error()
+    rc = lib.dmn_sru_fwd(1, None, 1, None, 1, None, None, 4, 1, 8, 3, 1, 1.0, 0, None)
+    assert rc < 0 and b"highway" in lib.dmn_last_error()
+    with pytest.raises(RuntimeError, match="bad sizes"):
+        _lib.call("dmn_dynfilter_fwd", 1, 1, 1, 0, 1, 1, 1, 1, None)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libdmn_hip.so")
+    with pytest.raises(RuntimeError, match="no fallback"):
+        _lib.load()
+
+
+def test_cpu_tensors_raise_no_cpu_fallback():
+    net = dms_amd.BaseDMN(20, emb_size=8, hid_size=8, vis_size=16, num_filters=2, mixed_size=8,
+                          hid_mixed_size=8, lang_layers=1, mixed_layers=1, pretrained=False)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net.hot_path(torch.zeros(1, 16, 2, 2), torch.zeros(1, 3, dtype=torch.long))
+
+
+@pytest.mark.parametrize("hr", [True, False])
+def test_state_dict_matches_reference(hr):
+    g = load_golden("dmn_state_keys_highres" if hr else "dmn_state_keys_lowres")
+    kw = dict(upsampling_mode="bilinear") if hr else {}
+    net = dms_amd.DMN(100, num_filters=10, lang_layers=3, mix_we=True, pretrained=False,
+                      high_res=hr, **kw)
+    sd = net.state_dict()
+    keys = sorted(sd)
+    assert keys == list(g["keys"])
+    assert [str(tuple(sd[k].shape)) for k in keys] == list(g["shapes"])
+
+
+def test_ctor_defaults_match_reference_signature():
+    import inspect
+    sig = inspect.signature(dms_amd.DMN.__init__)
+    d = {k: v.default for k, v in sig.parameters.items() if v.default is not inspect._empty}
+    assert d == dict(emb_size=1000, hid_size=1000, vis_size=2688, num_filters=1, mixed_size=1000,
+                     hid_mixed_size=1005, lang_layers=2, mixed_layers=3, backend='dpn92',
+                     mix_we=False, lstm=False, pretrained=True, extra=True, high_res=False,
+                     upsampling_mode='bilineal', upsampling_size=3,
+                     upsampling_amplification=32, dmn_freeze=False)
+    sig = inspect.signature(dms_amd.BaseDMN.__init__)
+    d = {k: v.default for k, v in sig.parameters.items() if v.default is not inspect._empty}
+    assert d == dict(emb_size=1000, hid_size=1000, vis_size=2688, num_filters=10,
+                     mixed_size=1000, hid_mixed_size=1005, lang_layers=3, mixed_layers=3,
+                     backend='dpn92', mix_we=True, lstm=False, pretrained=True, extra=True,
+                     high_res=False)
+
+
+def test_lenient_load_state_dict_copies_only_matching_sizes():
+    kw = dict(emb_size=8, hid_size=8, vis_size=16, num_filters=2, mixed_size=8, lang_layers=1,
+              mixed_layers=2, pretrained=False, mix_we=True)
+    low = dms_amd.DMN(20, hid_mixed_size=8, high_res=False, **kw)
+    other = dms_amd.DMN(20, hid_mixed_size=12, high_res=False, **kw)
+    before = {k: v.clone() for k, v in other.state_dict().items()}
+    other.load_state_dict(low.state_dict())
+    after = other.state_dict()
+    assert torch.equal(after["langvis.emb.weight"], low.state_dict()["langvis.emb.weight"])
+    # different size (k=4, 12 wide): untouched
+    k = "langvis.mrnn.rnn_lst.0.weight"
+    assert after[k].shape != low.state_dict()[k].shape and torch.equal(after[k], before[k])
+    # pretrained=True would download: refused
+    with pytest.raises(RuntimeError, match="download"):
+        dms_amd.DMN(20, pretrained=True)
+
+
+def test_product_never_imports_oracle_or_reference():
+    pat = re.compile(r"^\s*(from|import)\s+(oracle|tests|dmn_pytorch|sru\b)", re.M)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "dms_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not pat.search(text), f
+                assert "/root/reference" not in text, f
+
+
+def test_sru_module_surface():
+    rnn = dms_amd.SRU(6, 9, num_layers=3)
+    shapes = {k: tuple(v.shape) for k, v in rnn.state_dict().items()}
+    assert shapes == {"rnn_lst.0.weight": (6, 36), "rnn_lst.0.bias": (18,),
+                      "rnn_lst.1.weight": (9, 27), "rnn_lst.1.bias": (18,),
+                      "rnn_lst.2.weight": (9, 27), "rnn_lst.2.bias": (18,)}
+    assert rnn.rnn_lst[0].k == 4 and rnn.rnn_lst[1].k == 3
+    w = rnn.rnn_lst[0].weight
+    assert float(w.abs().max()) <= (3.0 / 6) ** 0.5 + 1e-6 and float(rnn.rnn_lst[0].bias.abs().sum()) == 0
+    with pytest.raises(NotImplementedError):
+        dms_amd.SRU(4, 4, bidirectional=True)

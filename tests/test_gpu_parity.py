@@ -1,0 +1,349 @@
+"""GPU parity tests (-m gpu): every HIP entry point, called through the C ABI, against the
+CPU oracle on the same seeded inputs; the model-level path against the reference's golden
+vectors; and size-independent properties at BASELINE.json's full sizes.
+
+Tolerances: fp32, logits within 1e-4 relative (BASELINE.json north_star); kernels use
+v_exp_f32 / v_rcp_f32 (1 ulp) so element-wise checks use rtol 1e-4 + atol 1e-5 at most
+and in practice sit near 1e-6.
+"""
+import numpy as np
+import pytest
+import torch
+
+import dms_amd
+from dms_amd import _lib, ops
+from oracle import dmn_ref, sru_ref
+from oracle.detgen import det_fill_state, det_ints, det_uniform
+from tests.util import base_inputs, cfg_from_golden, load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), "these tests need a real MI355X"
+    _lib.load()
+
+
+def _case(T, B, d, k, seed):
+    u = det_uniform((T, B, d, k), seed, 1.5)
+    x = det_uniform((T, B, d), seed + 1, 1.0) if k == 3 else None
+    bias = det_uniform((2 * d,), seed + 2, 0.5)
+    c0 = det_uniform((B, d), seed + 3, 1.0)
+    return u, x, bias, c0
+
+
+def _g(t):
+    return None if t is None else t.to(DEV)
+
+
+def _np(t):
+    return None if t is None else t.numpy()
+
+
+SRU_SHAPES = [(1, 1, 5, 3), (7, 3, 5, 4), (64, 1, 64, 3), (33, 2, 21, 4), (100, 3, 1005, 4),
+              (100, 3, 1005, 3), (257, 1, 130, 3), (0, 2, 4, 3), (25, 1, 1, 4), (23, 2, 63, 3)]
+
+
+@pytest.mark.parametrize("T,B,d,k", SRU_SHAPES)
+@pytest.mark.parametrize("act", ["tanh", "relu"])
+def test_sru_fwd_matches_oracle(T, B, d, k, act):
+    u, x, bias, c0 = _case(T, B, d, k, 41)
+    h_ref, c_ref, cl_ref = sru_ref.sru_fwd_c(_np(u), _np(x), _np(bias), _np(c0), act, 1.0)
+    h, c_all, c_last = ops.sru_forward_raw(_g(u), _g(x), _g(bias), _g(c0), act, 1.0, 0,
+                                           want_c=True, nchunks=1)
+    np.testing.assert_allclose(h.cpu().numpy(), h_ref, rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(c_all.cpu().numpy(), c_ref, rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(c_last.cpu().numpy(), cl_ref, rtol=1e-4, atol=2e-6)
+    # inference variant: no c store, c0 = NULL, only the tail of h
+    h_t0 = T // 3
+    h_ref2, _, cl2 = sru_ref.sru_fwd_c(_np(u), _np(x), _np(bias), None, act, 1.0, want_c=False)
+    h2, none_c, c_last2 = ops.sru_forward_raw(_g(u), _g(x), _g(bias), None, act, 1.0, h_t0,
+                                              want_c=False, nchunks=1)
+    assert none_c is None and h2.shape == (T - h_t0, B, d)
+    np.testing.assert_allclose(h2.cpu().numpy(), h_ref2[h_t0:], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(c_last2.cpu().numpy(), cl2, rtol=1e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize("depth", ["4", "8", "16", "24"])
+def test_sru_fwd_every_prefetch_depth(depth, monkeypatch):
+    # DMN_SRU_DEPTH forces the register-ring depth; T % depth != 0 exercises the tails
+    monkeypatch.setenv("DMN_SRU_DEPTH", depth)
+    T, B, d, k = 61, 2, 70, 4
+    u, x, bias, c0 = _case(T, B, d, k, 47)
+    h_ref, _, _ = sru_ref.sru_fwd_c(_np(u), None, _np(bias), _np(c0), "tanh", 1.0)
+    h, _, _ = ops.sru_forward_raw(_g(u), None, _g(bias), _g(c0), "tanh", 1.0, 0, nchunks=1)
+    np.testing.assert_allclose(h.cpu().numpy(), h_ref, rtol=1e-4, atol=2e-6)
+    u, x, bias, c0 = _case(T, B, d, 3, 48)
+    h_ref, _, _ = sru_ref.sru_fwd_c(_np(u), _np(x), _np(bias), _np(c0), "tanh", 1.0)
+    h, _, _ = ops.sru_forward_raw(_g(u), _g(x), _g(bias), _g(c0), "tanh", 1.0, 0, nchunks=1)
+    np.testing.assert_allclose(h.cpu().numpy(), h_ref, rtol=1e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize("T,B,d,k,nch", [(640, 1, 1005, 4, 10), (640, 1, 1005, 3, 7),
+                                         (513, 2, 33, 3, 8), (5, 1, 9, 4, 4), (70, 1, 64, 3, 70)])
+def test_sru_fwd_time_parallel_scan_matches_oracle(T, B, d, k, nch):
+    u, x, bias, c0 = _case(T, B, d, k, 53)
+    h_ref, _, cl_ref = sru_ref.sru_fwd_c(_np(u), _np(x), _np(bias), _np(c0), "tanh", 1.0)
+    h_t0 = T // 2
+    h, _, c_last = ops.sru_forward_raw(_g(u), _g(x), _g(bias), _g(c0), "tanh", 1.0, h_t0,
+                                       want_c=False, nchunks=nch)
+    np.testing.assert_allclose(h.cpu().numpy(), h_ref[h_t0:], rtol=1e-4, atol=3e-6)
+    np.testing.assert_allclose(c_last.cpu().numpy(), cl_ref, rtol=1e-4, atol=3e-6)
+
+
+@pytest.mark.parametrize("T,B,d,k", [(1, 1, 5, 3), (9, 3, 5, 4), (40, 2, 17, 3), (100, 2, 1005, 4),
+                                     (67, 3, 130, 3), (8, 1, 64, 4), (0, 1, 3, 3)])
+@pytest.mark.parametrize("act", ["tanh", "relu"])
+def test_sru_bwd_matches_oracle(T, B, d, k, act):
+    u, x, bias, c0 = _case(T, B, d, k, 61)
+    gh = det_uniform((T, B, d), 67, 1.0)
+    gl = det_uniform((B, d), 68, 1.0)
+    _, c_all, _ = sru_ref.sru_fwd_c(_np(u), _np(x), _np(bias), _np(c0), act, 1.0)
+    gu_r, gx_r, gb_r, gc0_r = sru_ref.sru_bwd_c(_np(u), _np(x), _np(bias), _np(c0), c_all,
+                                                _np(gh), _np(gl), act, 1.0)
+    ug, xg, bg, cg = (_g(u).requires_grad_(True), _g(x).requires_grad_(True) if x is not None else None,
+                      _g(bias).requires_grad_(True), _g(c0).requires_grad_(True))
+    h, c_last = ops.sru_compute(ug, xg, bg, cg, act, 1.0)
+    ((h * _g(gh)).sum() + (c_last * _g(gl)).sum()).backward()
+    np.testing.assert_allclose(ug.grad.cpu().numpy(), gu_r, rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(bg.grad.cpu().numpy(), gb_r.sum(1).reshape(-1), rtol=2e-4, atol=5e-5)
+    np.testing.assert_allclose(cg.grad.cpu().numpy(), gc0_r, rtol=2e-4, atol=1e-5)
+    if x is not None:
+        np.testing.assert_allclose(xg.grad.cpu().numpy(), gx_r, rtol=2e-4, atol=1e-5)
+
+
+def test_sru_module_stack_matches_oracle_and_autograd():
+    torch.manual_seed(5)
+    rnn = dms_amd.SRU(12, 20, num_layers=3).to(DEV)
+    ref = sru_ref.SRURef(12, 20, num_layers=3)
+    ref.load_state_dict({k: v.cpu() for k, v in rnn.state_dict().items()})
+    x = det_uniform((17, 2, 12), 71, 1.0)
+    xg = x.to(DEV).requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    h, c = rnn(xg)
+    hr, cr = ref(xr)
+    assert h.shape == (17, 2, 20) and c.shape == (3, 2, 20)
+    assert rel_err(h.detach().cpu(), hr.detach()) < 1e-5 and rel_err(c.detach().cpu(), cr.detach()) < 1e-5
+    w = det_uniform((17, 2, 20), 72, 1.0)
+    (h * w.to(DEV)).sum().backward()
+    (hr * w).sum().backward()
+    assert rel_err(xg.grad.cpu(), xr.grad) < 1e-4
+    for (n, p), (_, pr) in zip(rnn.named_parameters(), ref.named_parameters()):
+        assert rel_err(p.grad.cpu(), pr.grad) < 1e-4, n
+    with torch.no_grad():
+        h_tail, _ = rnn(xg, tail=5)
+    assert h_tail.shape == (5, 2, 20) and rel_err(h_tail.cpu(), hr.detach()[-5:]) < 1e-5
+
+
+@pytest.mark.parametrize("H,W", [(10, 10), (16, 16), (16, 12), (1, 1), (3, 5)])
+def test_cat_coords_bit_exact_vs_reference_golden(H, W):
+    g = load_golden("spatial")["s_%d_%d" % (H, W)]
+    vis = det_uniform((2, 5, H, W), 81, 1.0)
+    V = ops.cat_coords(vis.to(DEV)).cpu()
+    assert torch.equal(V[:, :5], vis)
+    for b in range(2):
+        np.testing.assert_array_equal(V[b, 5:].numpy(), g[0])
+    s = dms_amd.BaseDMN.generate_spatial_batch(H, W).cpu().numpy()
+    np.testing.assert_array_equal(s, g)
+
+
+@pytest.mark.parametrize("B,L,K,C,S", [(1, 20, 10, 2696, 256), (2, 20, 10, 2696, 100), (3, 5, 3, 40, 12),
+                                       (2, 4, 1, 37, 15), (1, 1, 1, 1, 1), (2, 7, 10, 130, 66)])
+def test_dynfilter_matches_per_word_conv2d(B, L, K, C, S):
+    V = det_uniform((B, C, S), 91, 1.0)
+    Fi = torch.sigmoid(det_uniform((L, B, K, C), 92, 2.0))
+    P = ops.dynfilter(V.to(DEV), Fi.to(DEV)).cpu()
+    # the reference's formulation: one F.conv2d per word, per sample (dmn.py:178-184)
+    ref = torch.stack([torch.cat([torch.nn.functional.conv2d(
+        V[b].double().view(1, C, S, 1), Fi[t, b].double().view(K, C, 1, 1)).view(1, K, S)
+        for b in range(B)]) for t in range(L)])
+    assert P.shape == (L, B, K, S)
+    assert rel_err(P, ref) < 2e-6
+
+
+def test_dynfilter_bwd_matches_autograd():
+    B, L, K, C, S = 2, 5, 3, 41, 18
+    V = det_uniform((B, C, S), 93, 1.0)
+    Fi = det_uniform((L, B, K, C), 94, 1.0)
+    gP = det_uniform((L, B, K, S), 95, 1.0)
+    Vg, Fg = V.to(DEV).requires_grad_(True), Fi.to(DEV).requires_grad_(True)
+    (ops.dynfilter(Vg, Fg) * gP.to(DEV)).sum().backward()
+    Vr, Fr = V.clone().double().requires_grad_(True), Fi.clone().double().requires_grad_(True)
+    (torch.einsum("tbkc,bcs->tbks", Fr, Vr) * gP.double()).sum().backward()
+    assert rel_err(Vg.grad.cpu(), Vr.grad) < 2e-6 and rel_err(Fg.grad.cpu(), Fr.grad) < 2e-6
+
+
+def _mix_ref(A, Bt, P, Wp):
+    # Q[(s*L+t), b, m]
+    L, B, K, S = P.shape
+    q = A.permute(1, 0, 2)[:, None] + Bt[None] + torch.einsum("mk,tbks->stbm", Wp, P)
+    return q.reshape(S * L, B, -1)
+
+
+@pytest.mark.parametrize("B,L,K,S,M", [(2, 20, 10, 100, 1000), (1, 5, 3, 12, 16), (3, 4, 1, 7, 10),
+                                       (2, 3, 17, 9, 8), (1, 2, 20, 5, 7)])
+def test_mix_bcast_add_matches_einsum(B, L, K, S, M):
+    A = det_uniform((B, S, M), 101, 1.0)
+    Bt = det_uniform((L, B, M), 102, 1.0)
+    P = det_uniform((L, B, K, S), 103, 1.0)
+    Wfull = det_uniform((M, 50 + K), 104, 1.0)
+    Wp = Wfull.to(DEV)[:, 50:]                       # strided column slice like comb_conv's
+    Q = ops.mix_bcast_add(A.to(DEV), Bt.to(DEV), P.to(DEV), Wp).cpu()
+    ref = _mix_ref(A.double(), Bt.double(), P.double(), Wfull[:, 50:].double())
+    assert Q.shape == (S * L, B, M)
+    assert rel_err(Q, ref) < 2e-6
+
+
+def test_mix_bcast_add_bwd_matches_autograd():
+    B, L, K, S, M = 2, 5, 3, 11, 24
+    A, Bt = det_uniform((B, S, M), 111, 1.0), det_uniform((L, B, M), 112, 1.0)
+    P, Wp = det_uniform((L, B, K, S), 113, 1.0), det_uniform((M, K), 114, 1.0)
+    gQ = det_uniform((S * L, B, M), 115, 1.0)
+    gs = [t.to(DEV).requires_grad_(True) for t in (A, Bt, P, Wp)]
+    (ops.mix_bcast_add(*gs) * gQ.to(DEV)).sum().backward()
+    rs = [t.clone().double().requires_grad_(True) for t in (A, Bt, P, Wp)]
+    (_mix_ref(*rs) * gQ.double()).sum().backward()
+    for a, b, n in zip(gs, rs, "A Bt P Wp".split()):
+        assert rel_err(a.grad.cpu(), b.grad) < 3e-6, n
+
+
+@pytest.mark.parametrize("B,Cx,Cf,H,W", [(2, 3, 5, 4, 6), (1, 7, 0, 3, 3), (1, 0, 4, 1, 1), (2, 2, 2, 5, 7),
+                                         (1, 33, 31, 16, 16)])
+def test_cat_upsample2x_matches_torch(B, Cx, Cf, H, W):
+    x, f = det_uniform((B, Cx, H, W), 121, 1.0), det_uniform((B, Cf, H, W), 122, 1.0)
+    out = ops.cat_upsample2x(x.to(DEV), f.to(DEV)).cpu()
+    ref = torch.nn.functional.interpolate(torch.cat([x, f], 1), scale_factor=2, mode="bilinear",
+                                          align_corners=False)
+    assert out.shape == ref.shape
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_cat_upsample2x_bwd_matches_autograd():
+    B, Cx, Cf, H, W = 2, 3, 2, 5, 6
+    x, f = det_uniform((B, Cx, H, W), 123, 1.0), det_uniform((B, Cf, H, W), 124, 1.0)
+    g = det_uniform((B, Cx + Cf, 2 * H, 2 * W), 125, 1.0)
+    xg, fg = x.to(DEV).requires_grad_(True), f.to(DEV).requires_grad_(True)
+    (ops.cat_upsample2x(xg, fg) * g.to(DEV)).sum().backward()
+    xr, fr = x.clone().requires_grad_(True), f.clone().requires_grad_(True)
+    (torch.nn.functional.interpolate(torch.cat([xr, fr], 1), scale_factor=2, mode="bilinear",
+                                     align_corners=False) * g).sum().backward()
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(fg.grad.cpu().numpy(), fr.grad.numpy(), rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------
+# model level: the reference's own outputs (tests/golden, made by oracle/gen_golden.py)
+# ------------------------------------------------------------------------------------
+def _product_base(name):
+    g = load_golden(name)
+    cfg = cfg_from_golden(g)
+    H, W, L, D = int(g["H"]), int(g["W"]), int(g["L"]), int(g["dict_size"])
+    net = dms_amd.BaseDMN(D, emb_size=cfg["emb_size"], hid_size=cfg["hid_size"],
+                          vis_size=cfg["vis_size"], num_filters=cfg["num_filters"],
+                          mixed_size=cfg["mixed_size"], hid_mixed_size=cfg["hid_mixed_size"],
+                          lang_layers=cfg["lang_layers"], mixed_layers=cfg["mixed_layers"],
+                          mix_we=cfg["mix_we"], pretrained=False, high_res=cfg["high_res"])
+    net.base = torch.nn.Identity()                      # golden vectors start after the backbone
+    state = det_fill_state(net.state_dict())
+    torch.nn.Module.load_state_dict(net, state)
+    net = net.to(DEV).eval()
+    vis, lang = base_inputs(cfg, H, W, L, D)
+    return net, vis, lang, g, cfg, state
+
+
+@pytest.mark.parametrize("name", ["base_tiny_k3", "base_tiny_k4", "base_tiny_k4_nowe_hr",
+                                  "base_full_320_lowres", "base_full_512_highres_feat"])
+def test_hot_path_matches_reference_golden(name):
+    net, vis, lang, g, cfg, _ = _product_base(name)
+    with torch.no_grad():
+        out = net.hot_path(vis.to(DEV), lang.to(DEV)).cpu()
+    assert tuple(out.shape) == g["out"].shape
+    assert rel_err(out, g["out"]) < 1e-4                       # north_star tolerance
+    if out.shape[1] == 1:                                      # thresholded mask agreement
+        agree = ((out > 0) == (torch.from_numpy(g["out"]) > 0)).float().mean().item()
+        assert agree >= 0.999
+
+
+def test_hot_path_batched_equals_independent_batch1_forwards():
+    net, vis, lang, g, cfg, state = _product_base("base_tiny_k4")
+    B = 3
+    visb = torch.cat([vis, det_uniform(tuple(vis.shape), 131, 1.0), det_uniform(tuple(vis.shape), 132, 1.0)])
+    langb = torch.cat([lang, det_ints(tuple(lang.shape), 133, 50), det_ints(tuple(lang.shape), 134, 50)])
+    with torch.no_grad():
+        out = net.hot_path(visb.to(DEV), langb.to(DEV)).cpu()
+        P = {"langvis." + k: v for k, v in state.items()}
+        ref = dmn_ref.hot_path(P, visb, langb, cfg)
+    assert out.shape == ref.shape == (B, 1, 4, 3)
+    assert rel_err(out, ref) < 1e-4
+    assert rel_err(out[:1], g["out"]) < 1e-4
+
+
+def test_upsampling_module_matches_reference_golden():
+    g = load_golden("upsample_small")
+    fch = [6, 5, 4, 3, 2]
+    up = dms_amd.UpsamplingModule(7, mode="bilinear", ker_size=3, amplification=8, feature_channels=fch)
+    up.load_state_dict(det_fill_state(up.state_dict()))
+    up = up.to(DEV).eval()
+    x = det_uniform((1, 7, 3, 4), 303, 1.0).to(DEV)
+    feats = [None, None, det_uniform((1, fch[2], 12, 16), 306, 1.0).to(DEV),
+             det_uniform((1, fch[1], 6, 8), 305, 1.0).to(DEV), det_uniform((1, fch[0], 3, 4), 304, 1.0).to(DEV)]
+    with torch.no_grad():
+        y = up(x, feats).cpu()
+    assert rel_err(y, g["out"]) < 1e-4
+    feats = [None, None, det_uniform((1, fch[2], 13, 15), 309, 1.0).to(DEV),
+             det_uniform((1, fch[1], 7, 9), 308, 1.0).to(DEV), det_uniform((1, fch[0], 4, 5), 307, 1.0).to(DEV)]
+    with torch.no_grad():
+        y = up(x, feats).cpu()
+    assert rel_err(y, g["out_mis"]) < 1e-4
+
+
+def test_whole_dmn_matches_reference_end_to_end():
+    """Reference DMN incl. its own DPN92 on a 64 px image, high-res head (golden e2e)."""
+    g = load_golden("dmn_e2e_64px_highres")
+    net = dms_amd.DMN(100, num_filters=10, lang_layers=3, mix_we=True, pretrained=False,
+                      high_res=True, upsampling_mode="bilinear", upsampling_amplification=32)
+    torch.nn.Module.load_state_dict(net, det_fill_state(net.state_dict()))
+    net = net.to(DEV).eval()
+    img = det_uniform((1, 3, 64, 64), 404, 1.0).to(DEV)
+    words = det_ints((1, 6), 405, 100).to(DEV)
+    with torch.no_grad():
+        vis, feats = net.langvis.base(img)
+        y = net(img, words).cpu()
+    assert rel_err(vis.cpu(), g["vis"]) < 1e-4                 # backbone (MIOpen) vs reference CPU
+    assert rel_err(feats[3].cpu(), g["feat3"]) < 1e-4
+    assert y.shape == (1, 1, 64, 64)
+    assert rel_err(y, g["out"]) < 1e-4
+    agree = ((y > 0) == (torch.from_numpy(g["out"]) > 0)).float().mean().item()
+    assert agree >= 0.999
+
+
+# ------------------------------------------------------------------------------------
+# full-size properties (BASELINE.json configs 2 and 5 shapes; no CPU oracle at this size)
+# ------------------------------------------------------------------------------------
+def test_sru_full_size_chunked_equals_whole_and_column_subset_oracle():
+    """Config-5-like: T=4096, d=1000, k=3 (B reduced to 16 to bound memory/time).
+    (i) splitting time in two calls with the carried c equals one call (recurrence
+    semantics); (ii) a random subset of columns matches the CPU oracle run on that subset
+    only (columns are independent)."""
+    T, B, d, k = 4096, 16, 1000, 3
+    gen = torch.Generator(device=DEV).manual_seed(1111)
+    u = torch.randn((T, B, d, k), device=DEV, generator=gen)
+    x = torch.randn((T, B, d), device=DEV, generator=gen)
+    bias = 0.1 * torch.randn((2 * d,), device=DEV, generator=gen)
+    h, _, cl = ops.sru_forward_raw(u, x, bias, None, "tanh", 1.0, nchunks=1)
+    Th = 1500
+    h1, _, c1 = ops.sru_forward_raw(u[:Th].contiguous(), x[:Th].contiguous(), bias, None, "tanh", 1.0, nchunks=1)
+    h2, _, c2 = ops.sru_forward_raw(u[Th:].contiguous(), x[Th:].contiguous(), bias, c1, "tanh", 1.0, nchunks=1)
+    assert torch.equal(torch.cat([h1, h2]), h) and torch.equal(c2, cl)
+    cols = torch.tensor([0, 1, 63, 64, 999, 1000, 7777, B * d - 1])
+    us = u.view(T, B * d, k)[:, cols].cpu().contiguous().view(T, 1, len(cols), k)
+    xs = x.view(T, B * d)[:, cols].cpu().contiguous().view(T, 1, len(cols))
+    bj = torch.cat([bias[:d][cols % d], bias[d:][cols % d]]).cpu()
+    h_ref, _, _ = sru_ref.sru_fwd_c(us.numpy(), xs.numpy(), bj.numpy(), None, "tanh", 1.0)
+    got = h.view(T, B * d)[:, cols].cpu().numpy()
+    np.testing.assert_allclose(got, h_ref[:, 0], rtol=1e-4, atol=3e-6)
+    # time-parallel variant agrees at full length as well
+    h3, _, c3 = ops.sru_forward_raw(u, x, bias, None, "tanh", 1.0, nchunks=16)
+    assert rel_err(h3, h) < 1e-5 and rel_err(c3, cl) < 1e-5
