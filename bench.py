@@ -1,0 +1,290 @@
+#!/usr/bin/env python
+# -*- coding: utf-8 -*-
+"""bench.py -- the BASELINE.json metric on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 32] [--workload dmn512|msru_stress]
+
+Workload `dmn512` (default) = BASELINE.json configs[1]: DMN high-res 512 px inference
+(dpn92, num_filters 10, lang_layers 3, mix_we, upsampling amplification 32, random init,
+20-token synthetic queries), batch 32 per GPU, inputs resident in HBM before the timed
+region.  A step = one forward over one batch.  N > 1: one process per GPU (torchrun), the
+batch of (image, query) pairs is sharded, no data-path collective ("weak" scaling: 32 per
+GPU, so N = 8 is configs[2]'s 256).  value = total queries / max-over-ranks wall time.
+
+The same JSON line carries
+  roofline     : the dominant hand-written kernel (the mSRU scan), algorithmic bytes per
+                 launch / average launch duration measured live with HIP events on the
+                 launch stream during the timed steps, vs the 8 TB/s HBM peak;
+  cpu_baseline : the CPU oracle (oracle/: plain-C scan + pure-torch reference-shaped glue +
+                 torch-CPU DPN92) on a bounded sample of the same workload (a few batch-1
+                 queries) on this box's host cores -- rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
+SEED = 1111                    # reference default seed (train.py:75)
+
+
+class LaunchTimer(object):
+    """Brackets every libdmn_hip entry-point call with HIP events on the launch stream."""
+
+    def __init__(self):
+        self.records = []
+        self.enabled = False
+
+    def begin(self, name, args):
+        if not self.enabled:
+            return None
+        a = torch.cuda.Event(enable_timing=True)
+        a.record()
+        return (name, args, a)
+
+    def end(self, token):
+        if token is None:
+            return
+        name, args, a = token
+        b = torch.cuda.Event(enable_timing=True)
+        b.record()
+        self.records.append((name, args, a, b))
+
+    @staticmethod
+    def describe(name, args):
+        """(variant label, algorithmic bytes of this launch) -- SURVEY.md section 8(d)."""
+        if name in ("dmn_sru_fwd", "dmn_sru_fwd_scan"):
+            T, B, d, k = args[7:11]
+            h_t0 = args[13]
+            rd = (4 * k + (4 if k == 3 else 0)) * T * B * d
+            wr = 4 * (T - h_t0) * B * d
+            if name == "dmn_sru_fwd" and args[5]:           # c_all stored (training)
+                wr += 4 * T * B * d
+            label = "sru_fwd k=%d T=%d cols=%d%s%s" % (
+                k, T, B * d, " tail" if h_t0 else "", " scan" if name.endswith("scan") else "")
+            return label, rd + wr
+        if name == "dmn_dynfilter_fwd":
+            B, L, K, C, S = args[3:8]
+            return "dynfilter_fwd", 4 * B * (C * S + L * K * C + L * K * S)
+        if name == "dmn_mix_bcast_add":
+            B, L, K, S, M = args[6:11]
+            return "mix_bcast_add", 4 * B * (S * M + L * M + L * K * S + S * L * M)
+        if name == "dmn_cat_coords":
+            B, C, H, W = args[2:6]
+            return "cat_coords", 4 * B * H * W * (2 * C + 8)
+        if name == "dmn_cat_upsample2x":
+            B, Cx, Cf, H, W = args[3:8]
+            return "cat_upsample2x %dx%d" % (H, W), 4 * B * (Cx + Cf) * H * W * 5
+        return name, 0
+
+    def summary(self):
+        agg = {}
+        for name, args, a, b in self.records:
+            label, nbytes = self.describe(name, args)
+            e = agg.setdefault(label, {"calls": 0, "ms": 0.0, "bytes": 0})
+            e["calls"] += 1
+            e["ms"] += a.elapsed_time(b)
+            e["bytes"] += nbytes
+        out = []
+        for label, e in agg.items():
+            avg_ms = e["ms"] / e["calls"]
+            gbs = (e["bytes"] / e["calls"]) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            out.append({"kernel": label, "calls": e["calls"], "avg_ms": round(avg_ms, 4),
+                        "total_ms": round(e["ms"], 3),
+                        "algorithmic_bytes_per_launch": e["bytes"] // e["calls"],
+                        "achieved_GBs": round(gbs, 1), "frac_of_8TBs": round(gbs / HBM_PEAK_GBS, 4)})
+        out.sort(key=lambda r: -r["total_ms"])
+        return out
+
+
+def build_model(device, high_res=True):
+    import dms_amd
+    torch.manual_seed(SEED)
+    net = dms_amd.DMN(1000, num_filters=10, lang_layers=3, mix_we=True, pretrained=False,
+                      high_res=high_res, upsampling_mode="bilinear",
+                      upsampling_amplification=32)
+    return net.to(device).eval()
+
+
+def cpu_baseline_dmn(net, reps, threads):
+    """CPU oracle on batch-1 queries of the same workload: torch-CPU DPN92 + reference-
+    shaped hot path (oracle.dmn_ref, plain-C SRU scan) + reference-shaped upsampling."""
+    from oracle import dmn_ref, sru_ref
+    torch.set_num_threads(threads)
+    sru_ref.set_threads(threads)
+    cpu_net = build_model("cpu")
+    torch.nn.Module.load_state_dict(cpu_net, {k: v.cpu() for k, v in net.state_dict().items()})
+    P = dict(cpu_net.state_dict())
+    cfg = dict(num_filters=10, vis_size=2688, lang_layers=3, mixed_layers=3, mix_we=True,
+               high_res=True)
+    g = torch.Generator().manual_seed(SEED)
+    img = torch.randn(1, 3, 512, 512, generator=g)
+    words = torch.randint(0, 1000, (1, 20), generator=g)
+    times, out = [], None
+    with torch.no_grad():
+        for i in range(reps + 1):
+            t0 = time.perf_counter()
+            vis, feats = cpu_net.langvis.base(img)
+            x = dmn_ref.hot_path_single(P, vis, words, cfg, use_c=True)
+            out = dmn_ref.upsampling(P, x, feats, 5)
+            if i:                                          # first pass is warm-up
+                times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(1.0 / med, 4), "unit": "queries/s", "cores": threads, "kind": "port",
+            "sample": "%d batch-1 512px high-res queries (median of %d after 1 warm-up): torch-CPU "
+                      "DPN92 + oracle/dmn_ref hot path (C scan, OpenMP) + oracle upsampling"
+                      % (reps, reps),
+            "seconds_per_query": round(med, 3)}, (img, words, out)
+
+
+def run_msru_stress(device, steps, warmup, timer):
+    """BASELINE.json configs[4]: standalone scan, T = 64*64, hidden 1000, batch 128, k = 3."""
+    from dms_amd import ops
+    T, B, d, k = 4096, 128, 1000, 3
+    g = torch.Generator(device=device).manual_seed(SEED)
+    u = torch.randn((T, B, d, k), device=device, generator=g)
+    x = torch.randn((T, B, d), device=device, generator=g)
+    bias = 0.1 * torch.randn((2 * d,), device=device, generator=g)
+    for _ in range(warmup):
+        ops.sru_forward_raw(u, x, bias, None, "tanh", 1.0, 0, want_c=False, nchunks=1)
+    torch.cuda.synchronize()
+    timer.records = []
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ops.sru_forward_raw(u, x, bias, None, "tanh", 1.0, 0, want_c=False, nchunks=1)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    timer.enabled = False
+    rows = timer.summary()
+    return rows[0], wall / steps * 1e3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="(image, query) pairs per GPU")
+    ap.add_argument("--workload", default="dmn512", choices=["dmn512", "msru_stress"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-reps", type=int, default=5)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from dms_amd import _lib
+    _lib.load()
+    timer = LaunchTimer()
+    _lib.TIMER = timer
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    if args.workload == "msru_stress":
+        row, ms = run_msru_stress(device, args.steps, args.warmup, timer)
+        line = {"metric": "mSRU achieved HBM GB/s (standalone scan, algorithmic 20 B per element)",
+                "value": row["achieved_GBs"], "unit": "GB/s", "n_gpus": 1, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "msru_stress T=4096 B=128 d=1000 k=3 (BASELINE configs[4])"},
+                "roofline": {"bound": "hbm", "achieved": row["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": row["frac_of_8TBs"], "traffic": None,
+                             "kernel": row["kernel"], "avg_launch_ms": row["avg_ms"]}}
+        if rank == 0:
+            print(json.dumps(line))
+        return
+
+    net = build_model(device)
+    B = args.batch
+    g = torch.Generator(device=device).manual_seed(SEED + rank)
+    img = torch.randn((B, 3, 512, 512), device=device, generator=g)
+    words = torch.randint(0, 1000, (B, 20), device=device, generator=g)
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = net(img, words)
+        torch.cuda.synchronize()
+        barrier()
+        timer.records = []
+        timer.enabled = True
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = net(img, words)
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        timer.enabled = False
+    assert tuple(out.shape) == (B, 1, 512, 512) and bool(torch.isfinite(out).all())
+
+    el = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    qps = world * B * args.steps / elapsed
+
+    kernels = timer.summary()
+    scans = [r for r in kernels if r["kernel"].startswith("sru_fwd") and "T=%d" % (256 * 20) in r["kernel"]]
+    dom = scans[0] if scans else kernels[0]
+    roofline = {"bound": "hbm", "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": dom["frac_of_8TBs"], "traffic": None,
+                "kernel": dom["kernel"], "avg_launch_ms": dom["avg_ms"],
+                "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"]}
+    hip_ms = sum(r["total_ms"] for r in kernels) / args.steps
+
+    line = {"metric": "queries/sec (whole node) high-res 512px DMN inference; mSRU achieved HBM GB/s",
+            "value": round(qps, 3), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "DMN high-res 512px inference (BASELINE configs[1]): dpn92, "
+                                   "num_filters 10, lang_layers 3, mix_we, amplification 32, "
+                                   "20-token queries, random init, eval()",
+                       "batch_per_gpu": B, "global_batch": B * world,
+                       "parallelism": "batch-sharded replicas, no collective"},
+            "roofline": roofline,
+            "msru_GBs": dom["achieved_GBs"],
+            "hip_kernels_ms_per_step": round(hip_ms, 3),
+            "hip_kernels": kernels}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        threads = min(os.cpu_count() or 1, 16)
+        cb, (cimg, cwords, cout) = cpu_baseline_dmn(net, args.cpu_reps, threads)
+        with torch.no_grad():
+            gout = net(cimg.to(device), cwords.to(device)).cpu()
+        cb["gpu_vs_oracle_rel_err"] = float((gout - cout).abs().max() / cout.abs().max())
+        cb["mask_agreement"] = float(((gout > 0) == (cout > 0)).float().mean())
+        line["cpu_baseline"] = cb
+        # configs[4] microbench beside it (same process, after the timed region)
+        row, ms = run_msru_stress(device, 20, 3, timer)
+        line["msru_stress"] = {"workload": "T=4096 B=128 d=1000 k=3", "achieved_GBs": row["achieved_GBs"],
+                               "frac_of_8TBs": row["frac_of_8TBs"], "avg_launch_ms": row["avg_ms"]}
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

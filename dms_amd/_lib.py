@@ -33,6 +33,10 @@ SIGNATURES = {
 
 _lib = None
 
+# Optional launch observer (bench.py installs one to bracket every entry-point call with
+# HIP events on the launch stream); None in normal use.  begin(name, args) -> token, end(token).
+TIMER = None
+
 
 def load():
     """Load (once) and type the library; raises if it is absent or stale."""
@@ -61,7 +65,11 @@ def load():
 def call(name, *args):
     """Invoke an entry point; non-zero status -> RuntimeError(dmn_last_error())."""
     lib = load()
+    timer = TIMER
+    token = timer.begin(name, args) if timer is not None else None
     rc = getattr(lib, name)(*args)
+    if timer is not None:
+        timer.end(token)
     if rc != 0:
         msg = lib.dmn_last_error()
         raise RuntimeError("%s failed (status %d): %s"

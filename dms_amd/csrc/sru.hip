@@ -289,7 +289,7 @@ static int check_common(const char *fn, const void *U, const void *x, const void
 {
     if ((!U && T > 0) || !bias) return fail(-1, "%s: U and bias must not be NULL", fn);
     if (k != 3 && k != 4) return fail(-2, "%s: k must be 3 or 4 (got %d)", fn, k);
-    if (k == 3 && !x) return fail(-3, "%s: k == 3 needs the highway input x", fn);
+    if (k == 3 && !x && T > 0) return fail(-3, "%s: k == 3 needs the highway input x", fn);
     if (k == 4 && x) return fail(-3, "%s: k == 4 takes the highway term from U[..,3]; x must be NULL", fn);
     if (T < 0 || B <= 0 || d <= 0) return fail(-4, "%s: bad sizes T=%d B=%d d=%d", fn, T, B, d);
     if ((long long)B * d > 0x7fffffffLL / 4) return fail(-5, "%s: B*d too large", fn);
@@ -350,9 +350,9 @@ extern "C" int dmn_sru_bwd(const float *U, const float *x, const float *bias, co
                            int T, int B, int d, int k, int act, float scale_x, void *stream)
 {
     if (int rc = check_common("dmn_sru_bwd", U, x, bias, T, B, d, k, act)) return rc;
-    if (!c_all || !grad_h || !grad_U || !grad_bias_part || !grad_c0)
+    if (((!c_all || !grad_h || !grad_U) && T > 0) || !grad_bias_part || !grad_c0)
         return fail(-1, "dmn_sru_bwd: c_all, grad_h, grad_U, grad_bias_part, grad_c0 must not be NULL");
-    if (k == 3 && !grad_x) return fail(-3, "dmn_sru_bwd: k == 3 needs grad_x");
+    if (k == 3 && !grad_x && T > 0) return fail(-3, "dmn_sru_bwd: k == 3 needs grad_x");
     if (k == 4 && ((uintptr_t)grad_U & 15)) return fail(-7, "dmn_sru_bwd: grad_U must be 16-byte aligned");
     const int ncols = B * d;
     dim3 grid((ncols + WAVE - 1) / WAVE);

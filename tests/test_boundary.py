@@ -39,7 +39,7 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     rc = lib.dmn_sru_fwd(1, None, 1, None, 1, None, None, 4, 1, 8, 5, 1, 1.0, 0, None)
     assert rc < 0
     assert b"k must be 3 or 4" in lib.dmn_last_error()
-    rc = lib.dmn_sru_fwd(1, None, 1, None, 1, None, None, 4, 1, 8, 3, 1, 1.0, 0, None)
+    rc = lib.dmn_sru_fwd(1, None, 1, None, 1, None, None, 4, 1, 8, 3, 1, 1.0, 0, None)  # T=4
     assert rc < 0 and b"highway" in lib.dmn_last_error()
     with pytest.raises(RuntimeError, match="bad sizes"):
         _lib.call("dmn_dynfilter_fwd", 1, 1, 1, 0, 1, 1, 1, 1, None)

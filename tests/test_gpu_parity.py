@@ -160,7 +160,7 @@ def test_dynfilter_matches_per_word_conv2d(B, L, K, C, S):
         V[b].double().view(1, C, S, 1), Fi[t, b].double().view(K, C, 1, 1)).view(1, K, S)
         for b in range(B)]) for t in range(L)])
     assert P.shape == (L, B, K, S)
-    assert rel_err(P, ref) < 2e-6
+    assert rel_err(P, ref) < 1e-5       # 2696-long fp32 sums vs an fp64 reference
 
 
 def test_dynfilter_bwd_matches_autograd():
@@ -172,7 +172,7 @@ def test_dynfilter_bwd_matches_autograd():
     (ops.dynfilter(Vg, Fg) * gP.to(DEV)).sum().backward()
     Vr, Fr = V.clone().double().requires_grad_(True), Fi.clone().double().requires_grad_(True)
     (torch.einsum("tbkc,bcs->tbks", Fr, Vr) * gP.double()).sum().backward()
-    assert rel_err(Vg.grad.cpu(), Vr.grad) < 2e-6 and rel_err(Fg.grad.cpu(), Fr.grad) < 2e-6
+    assert rel_err(Vg.grad.cpu(), Vr.grad) < 1e-5 and rel_err(Fg.grad.cpu(), Fr.grad) < 1e-5
 
 
 def _mix_ref(A, Bt, P, Wp):
@@ -193,7 +193,7 @@ def test_mix_bcast_add_matches_einsum(B, L, K, S, M):
     Q = ops.mix_bcast_add(A.to(DEV), Bt.to(DEV), P.to(DEV), Wp).cpu()
     ref = _mix_ref(A.double(), Bt.double(), P.double(), Wfull[:, 50:].double())
     assert Q.shape == (S * L, B, M)
-    assert rel_err(Q, ref) < 2e-6
+    assert rel_err(Q, ref) < 1e-5
 
 
 def test_mix_bcast_add_bwd_matches_autograd():
@@ -206,7 +206,7 @@ def test_mix_bcast_add_bwd_matches_autograd():
     rs = [t.clone().double().requires_grad_(True) for t in (A, Bt, P, Wp)]
     (_mix_ref(*rs) * gQ.double()).sum().backward()
     for a, b, n in zip(gs, rs, "A Bt P Wp".split()):
-        assert rel_err(a.grad.cpu(), b.grad) < 3e-6, n
+        assert rel_err(a.grad.cpu(), b.grad) < 1e-5, n
 
 
 @pytest.mark.parametrize("B,Cx,Cf,H,W", [(2, 3, 5, 4, 6), (1, 7, 0, 3, 3), (1, 0, 4, 1, 1), (2, 2, 2, 5, 7),
