@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libdmn_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = ["abi.hip", "sru.hip", "dynfilter.hip", "mix.hip", "glue.hip"]
+SOURCES = ["abi.hip", "sru.hip", "sru_fwd_k3.hip", "sru_fwd_k4.hip", "dynfilter.hip", "mix.hip", "glue.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -31,7 +31,7 @@ def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    hdrs = [os.path.join(CSRC, "common.h"),
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "sru_fwd.inl"),
             os.path.join(os.path.dirname(HERE), "include", "dmn_hip.h")]
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     objs, procs = [], []

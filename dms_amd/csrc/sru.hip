@@ -22,79 +22,17 @@ namespace dmn {
 
 struct __attribute__((packed, aligned(4))) F3 { float a, b, c; };
 
-// payload of one time step of one column: u0, u1 (forget), u2 (reset), highway input
-template <int K>
-__device__ __forceinline__ float4 load_step(const float *__restrict__ U,
-                                            const float *__restrict__ x,
-                                            size_t ncols, int col, int t)
-{
-    const size_t e = (size_t)t * ncols + col;
-    if (K == 4) {
-        return *reinterpret_cast<const float4 *>(U + e * 4);
-    } else {
-        const F3 v = *reinterpret_cast<const F3 *>(U + e * 3);
-        return make_float4(v.a, v.b, v.c, x[e]);
-    }
-}
+// forward scan kernels live in sru_fwd.inl (compiled per k in sru_fwd_k3.hip / sru_fwd_k4.hip)
+void launch_sru_fwd_k3(int act, bool store_c, int depth, dim3 grid, hipStream_t s, const float *U,
+                       const float *x, const float *bias, const float *c0, float *h, float *c_all,
+                       float *c_last, int T, int ncols, int d, float scale_x, int h_t0,
+                       int chunk_len, const float2 *carries);
+void launch_sru_fwd_k4(int act, bool store_c, int depth, dim3 grid, hipStream_t s, const float *U,
+                       const float *x, const float *bias, const float *c0, float *h, float *c_all,
+                       float *c_last, int T, int ncols, int d, float scale_x, int h_t0,
+                       int chunk_len, const float2 *carries);
+constexpr int WHOLE_SEQUENCE = 0x7fffffff / 2;   // chunk_len of the un-chunked scan
 
-template <int K, int ACT, int DEPTH, bool STORE_C>
-__global__ void __launch_bounds__(WAVE)
-sru_fwd_cols(const float *__restrict__ U, const float *__restrict__ x,
-             const float *__restrict__ bias, const float *__restrict__ c0,
-             float *__restrict__ h, float *__restrict__ c_all, float *__restrict__ c_last,
-             int T_total, int ncols, int d, float scale_x, int h_t0,
-             int chunk_len, const float2 *__restrict__ carries)
-{
-    const int col = blockIdx.x * WAVE + threadIdx.x;
-    if (col >= ncols) return;
-    const int j = col % d;
-    const float bf = bias[j], br = bias[j + d];
-    float cur = c0 ? c0[col] : 0.0f;
-    const size_t nc = (size_t)ncols;
-    const float sx = (K == 3) ? scale_x : 1.0f;
-    // time range of this workgroup: the whole sequence (gridDim.y == 1) or one chunk, whose
-    // incoming state is the composition of the preceding chunks' (A, B) aggregates
-    const int t_begin = blockIdx.y * chunk_len;
-    const int T = min(T_total, t_begin + chunk_len);
-    if (carries)
-        for (int cc = 0; cc < (int)blockIdx.y; ++cc) {
-            const float2 ab = carries[(size_t)cc * nc + col];
-            cur = __builtin_fmaf(ab.x, cur, ab.y);
-        }
-
-    if (T > t_begin) {
-        float4 ring[DEPTH];
-#pragma unroll
-        for (int i = 0; i < DEPTH; ++i)
-            ring[i] = load_step<K>(U, x, nc, col, t_begin + i < T ? t_begin + i : T - 1);
-
-        auto step = [&](const float4 v, int t) {
-            const float f = sigmoid_f(v.y + bf);
-            const float r = sigmoid_f(v.z + br);
-            cur = __builtin_fmaf(cur - v.x, f, v.x);
-            if (STORE_C) c_all[(size_t)t * nc + col] = cur;
-            const float xv = v.w * sx;
-            const float hv = __builtin_fmaf(act_fwd<ACT>(cur) - xv, r, xv);
-            if (t >= h_t0) h[(size_t)(t - h_t0) * nc + col] = hv;
-        };
-
-        int t0 = t_begin;
-        for (; t0 + DEPTH <= T; t0 += DEPTH) {
-#pragma unroll
-            for (int i = 0; i < DEPTH; ++i) {
-                const float4 v = ring[i];
-                int tn = t0 + i + DEPTH;
-                tn = tn < T ? tn : T - 1;          // clamped re-load at the tail: in bounds, unused
-                ring[i] = load_step<K>(U, x, nc, col, tn);
-                step(v, t0 + i);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < DEPTH; ++i)
-            if (t0 + i < T) step(ring[i], t0 + i);
-    }
-    if (c_last && blockIdx.y == gridDim.y - 1) c_last[col] = cur;
-}
 
 // Chunk aggregates for the time-parallel variant: the cell update is the affine map
 // c -> f*c + (1-f)*u0, so a chunk [t0, t1) composes to c_out = A*c_in + Bv with
@@ -254,36 +192,6 @@ static int depth_override()
     return e ? atoi(e) : -1;
 }
 
-template <int K, int ACT, bool STORE_C>
-static void launch_fwd(int depth, dim3 grid, hipStream_t s, const float *U, const float *x,
-                       const float *bias, const float *c0, float *h, float *c_all, float *c_last,
-                       int T, int ncols, int d, float scale_x, int h_t0, int chunk_len,
-                       const float2 *carries)
-{
-#define DMN_FWD(DEP)                                                                              \
-    hipLaunchKernelGGL((sru_fwd_cols<K, ACT, DEP, STORE_C>), grid, dim3(WAVE), 0, s, U, x, bias, \
-                       c0, h, c_all, c_last, T, ncols, d, scale_x, h_t0, chunk_len, carries)
-    if (depth <= 4) DMN_FWD(4);
-    else if (depth <= 8) DMN_FWD(8);
-    else if (depth <= 16) DMN_FWD(16);
-    else DMN_FWD(24);
-#undef DMN_FWD
-}
-
-template <int K, bool STORE_C>
-static void launch_fwd_act(int act, int depth, dim3 grid, hipStream_t s, const float *U,
-                           const float *x, const float *bias, const float *c0, float *h,
-                           float *c_all, float *c_last, int T, int ncols, int d, float scale_x,
-                           int h_t0, int chunk_len = 0x7fffffff / 2, const float2 *carries = nullptr)
-{
-    if (act == DMN_ACT_TANH)
-        launch_fwd<K, DMN_ACT_TANH, STORE_C>(depth, grid, s, U, x, bias, c0, h, c_all, c_last, T, ncols, d, scale_x, h_t0, chunk_len, carries);
-    else if (act == DMN_ACT_RELU)
-        launch_fwd<K, DMN_ACT_RELU, STORE_C>(depth, grid, s, U, x, bias, c0, h, c_all, c_last, T, ncols, d, scale_x, h_t0, chunk_len, carries);
-    else
-        launch_fwd<K, DMN_ACT_IDENTITY, STORE_C>(depth, grid, s, U, x, bias, c0, h, c_all, c_last, T, ncols, d, scale_x, h_t0, chunk_len, carries);
-}
-
 static int check_common(const char *fn, const void *U, const void *x, const void *bias, int T,
                         int B, int d, int k, int act)
 {
@@ -292,7 +200,8 @@ static int check_common(const char *fn, const void *U, const void *x, const void
     if (k == 3 && !x && T > 0) return fail(-3, "%s: k == 3 needs the highway input x", fn);
     if (k == 4 && x) return fail(-3, "%s: k == 4 takes the highway term from U[..,3]; x must be NULL", fn);
     if (T < 0 || B <= 0 || d <= 0) return fail(-4, "%s: bad sizes T=%d B=%d d=%d", fn, T, B, d);
-    if ((long long)B * d > 0x7fffffffLL / 4) return fail(-5, "%s: B*d too large", fn);
+    // 32-bit row offsets inside a 2 GiB descriptor window: DEPTH (<= 32) rows of U must fit
+    if ((long long)B * d * k * 4 * 33 >= 0x7fffffffLL) return fail(-5, "%s: B*d=%lld too large", fn, (long long)B * d);
     if (act < 0 || act > 2) return fail(-6, "%s: unknown activation %d", fn, act);
     if (k == 4 && ((uintptr_t)U & 15)) return fail(-7, "%s: U must be 16-byte aligned for k == 4", fn);
     return 0;
@@ -313,16 +222,11 @@ extern "C" int dmn_sru_fwd(const float *U, const float *x, const float *bias, co
     const int nwaves = (ncols + WAVE - 1) / WAVE;
     // bytes in flight must come from depth when there are few waves per CU
     int depth = depth_override();
-    if (depth <= 0) depth = (nwaves <= 4 * NUM_CU) ? 24 : (nwaves <= 8 * NUM_CU ? 16 : 8);
+    if (depth <= 0) depth = (nwaves <= 3 * NUM_CU) ? 32 : (nwaves <= 6 * NUM_CU ? 16 : 8);
     dim3 grid(nwaves);
     hipStream_t s = (hipStream_t)stream;
-    if (k == 3) {
-        if (c_all) launch_fwd_act<3, true>(act, depth, grid, s, U, x, bias, c0, h, c_all, c_last, T, ncols, d, scale_x, h_t0);
-        else       launch_fwd_act<3, false>(act, depth, grid, s, U, x, bias, c0, h, c_all, c_last, T, ncols, d, scale_x, h_t0);
-    } else {
-        if (c_all) launch_fwd_act<4, true>(act, depth, grid, s, U, x, bias, c0, h, c_all, c_last, T, ncols, d, scale_x, h_t0);
-        else       launch_fwd_act<4, false>(act, depth, grid, s, U, x, bias, c0, h, c_all, c_last, T, ncols, d, scale_x, h_t0);
-    }
+    if (k == 3) launch_sru_fwd_k3(act, c_all != nullptr, depth, grid, s, U, x, bias, c0, h, c_all, c_last, T, ncols, d, scale_x, h_t0, WHOLE_SEQUENCE, nullptr);
+    else        launch_sru_fwd_k4(act, c_all != nullptr, depth, grid, s, U, x, bias, c0, h, c_all, c_last, T, ncols, d, scale_x, h_t0, WHOLE_SEQUENCE, nullptr);
     return launch_status("dmn_sru_fwd");
 }
 
@@ -393,7 +297,7 @@ extern "C" int dmn_sru_fwd_scan(const float *U, const float *x, const float *bia
     float2 *carries = reinterpret_cast<float2 *>(workspace);
     if (k == 3) hipLaunchKernelGGL((sru_chunk_aggregate<3, 8>), grid, dim3(WAVE), 0, s, U, bias, carries, T, ncols, d, chunk_len);
     else        hipLaunchKernelGGL((sru_chunk_aggregate<4, 8>), grid, dim3(WAVE), 0, s, U, bias, carries, T, ncols, d, chunk_len);
-    if (k == 3) launch_fwd_act<3, false>(act, 8, grid, s, U, x, bias, c0, h, nullptr, c_last, T, ncols, d, scale_x, h_t0, chunk_len, carries);
-    else        launch_fwd_act<4, false>(act, 8, grid, s, U, x, bias, c0, h, nullptr, c_last, T, ncols, d, scale_x, h_t0, chunk_len, carries);
+    if (k == 3) launch_sru_fwd_k3(act, false, 8, grid, s, U, x, bias, c0, h, nullptr, c_last, T, ncols, d, scale_x, h_t0, chunk_len, carries);
+    else        launch_sru_fwd_k4(act, false, 8, grid, s, U, x, bias, c0, h, nullptr, c_last, T, ncols, d, scale_x, h_t0, chunk_len, carries);
     return launch_status("dmn_sru_fwd_scan");
 }

@@ -1,0 +1,303 @@
+// dms_amd/csrc/sru_fwd.inl -- SRU forward scan kernel template + launcher for ONE k.
+// Included by sru_fwd_k3.hip / sru_fwd_k4.hip (#define DMN_SRU_K first) so that the two
+// sets of instantiations compile in parallel.  See sru.hip for the C ABI.
+#include "common.h"
+
+namespace dmn {
+
+struct __attribute__((packed, aligned(4))) F3 { float a, b, c; };
+
+// ------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------
+// With B*d/64 <= 2 waves per CU each wave sits ALONE on a SIMD, where the in-order issue
+// of one wave (~4-5 cycles per instruction) bounds the scan as much as HBM does: the first
+// version of this kernel spent ~48 instructions and a branch per step (290 cycles/step).
+// Hence:
+//  (i)   gates folded to fma -> v_exp -> add -> v_rcp; tanh = 2*sigmoid(2c) - 1: 17 VALU/step;
+//  (ii)  buffer addressing: SRD base = wave-uniform row pointer re-based every DEPTH steps
+//        (2 GiB window, so tensors of any size work), lane byte offset in ONE constant VGPR,
+//        time step as an SGPR offset -> no per-step VALU address math;
+//  (iii) a ROLLING register ring: hipcc's own s_waitcnt placement drains the ring with
+//        vmcnt(0) at every loop header (measured: loads then only overlap one block of
+//        compute), so the loads are inline asm that hipcc does not count, and each slot is
+//        waited for with an exact counted vmcnt(N) naming the slot's registers "+v"
+//        (guide section 5.7 form ii).  N = VMEM ops issued after that slot's load; stores
+//        are compiler builtins, ordered against the asm by the "memory" clobber and counted
+//        here by hand.
+constexpr float LOG2E = 1.4426950408889634f;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void *base)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0x7fffffff, 0x00020000);
+}
+
+// raw-buffer SRD words for the asm loads (base, stride 0, 2 GiB window, dword format)
+__device__ __forceinline__ i32x4 make_srd(const void *base)
+{
+    const unsigned long long a = (unsigned long long)base;
+    i32x4 r;
+    r.x = (int)(a & 0xffffffffull);
+    r.y = (int)((a >> 32) & 0xffffull);
+    r.z = 0x7fffffff;
+    r.w = 0x00020000;
+    return r;
+}
+
+template <int K> struct Slot;
+template <> struct Slot<4> { f32x4 u; };
+template <> struct Slot<3> { f32x3 u; float x; };
+
+template <int I> struct IC { static constexpr int value = I; };
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(IC<I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// issue the loads of one time step into a ring slot (NOT waited for; see wait_slot).
+// The destination is "+v" (read-write), not "=v": tied to the register the slot already
+// lives in, so hipcc has no reason to load into a fresh register and v_mov it into the
+// loop-carried one BEFORE the data has landed (it did exactly that with "=v" for k = 3).
+__device__ __forceinline__ void issue_load(Slot<4> &s, i32x4 srdU, i32x4, unsigned offU, unsigned,
+                                           unsigned sU, unsigned)
+{
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(s.u) : "v"(offU), "s"(srdU), "s"(sU) : "memory");
+}
+__device__ __forceinline__ void issue_load(Slot<3> &s, i32x4 srdU, i32x4 srdX, unsigned offU,
+                                           unsigned offX, unsigned sU, unsigned sX)
+{
+    asm volatile("buffer_load_dwordx3 %0, %1, %2, %3 offen" : "+v"(s.u) : "v"(offU), "s"(srdU), "s"(sU) : "memory");
+    asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "+v"(s.x) : "v"(offX), "s"(srdX), "s"(sX) : "memory");
+}
+
+// wait until at most N younger VMEM operations are outstanding; naming the slot "+v" makes
+// every consumer of the slot depend on this statement
+template <int N>
+__device__ __forceinline__ void wait_slot(Slot<4> &s)
+{
+    constexpr int n = N > 63 ? 63 : N;
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(s.u) : "n"(n) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_slot(Slot<3> &s)
+{
+    constexpr int n = N > 63 ? 63 : N;
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(s.u), "+v"(s.x) : "n"(n) : "memory");
+}
+
+__device__ __forceinline__ float4 slot_values(const Slot<4> &s) { return make_float4(s.u.x, s.u.y, s.u.z, s.u.w); }
+__device__ __forceinline__ float4 slot_values(const Slot<3> &s) { return make_float4(s.u.x, s.u.y, s.u.z, s.x); }
+
+struct ScanPtrs {
+    const char *ldU, *ldX;   // row of the first step of the range (loads)
+    char *stH, *stC;         // row of the first step of the range (stores)
+};
+
+// n >= 1 steps starting at the rows in `p`; returns the carried cell state and leaves `p`
+// at row n.
+template <int K, int ACT, int DEPTH, bool STORE_C, bool STORE_H>
+__device__ __forceinline__ float scan_range(ScanPtrs &p, unsigned strideU, unsigned strideX,
+                                            unsigned offU, unsigned offX, int n, float cur,
+                                            float bf2, float br2, float sx)
+{
+    constexpr int NLD = (K == 3) ? 2 : 1;                       // VMEM loads per step
+    constexpr int NST = (STORE_H ? 1 : 0) + (STORE_C ? 1 : 0);  // VMEM stores per step
+    Slot<K> ring[DEPTH] = {};
+    const ScanPtrs start = p;
+
+    auto step = [&](const float4 v, rsrc_t rH, rsrc_t rC, int i) {
+        // sigmoid(u + b) = 1 / (1 + 2^(-(u + b) log2 e)), bias pre-multiplied into b?2
+        const float f = fast_rcp(1.0f + fast_exp2(__builtin_fmaf(v.y, -LOG2E, bf2)));
+        const float r = fast_rcp(1.0f + fast_exp2(__builtin_fmaf(v.z, -LOG2E, br2)));
+        cur = __builtin_fmaf(cur - v.x, f, v.x);
+        if (STORE_C)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(cur), rC, offX, i * strideX, 0);
+        if (STORE_H) {
+            const float xv = (K == 3) ? v.w * sx : v.w;
+            const float hv = __builtin_fmaf(act_fwd<ACT>(cur) - xv, r, xv);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hv), rH, offX, i * strideX, 0);
+        }
+    };
+
+    // Loads of one block: SRD base = first row of the block (re-based every block, uniform
+    // SALU arithmetic), row i of the block = SGPR offset i*stride.  CLAMP: rows past the end
+    // of the range re-read row n-1 (in bounds, value unused) so that the VMEM op count per
+    // step never changes; only the first and the last full block need it.
+    auto block_srds = [&](int row0, i32x4 &srdU, i32x4 &srdX, unsigned &limU, unsigned &limX) {
+        const int base = row0 < n - 1 ? row0 : n - 1;
+        const int lim = n - 1 - base;                            // >= 0
+        srdU = make_srd(start.ldU + (size_t)base * strideU);
+        srdX = make_srd(start.ldX + (size_t)base * strideX);
+        limU = (unsigned)lim * strideU;
+        limX = (unsigned)lim * strideX;
+    };
+    auto load_clamped = [&](Slot<K> &slot, i32x4 srdU, i32x4 srdX, unsigned limU, unsigned limX, int i) {
+        const unsigned sU = (unsigned)i * strideU, sX = (unsigned)i * strideX;
+        issue_load(slot, srdU, srdX, offU, offX, sU < limU ? sU : limU, sX < limX ? sX : limX);
+    };
+
+    // prologue: DEPTH steps in flight
+    {
+        i32x4 srdU, srdX; unsigned limU, limX;
+        block_srds(0, srdU, srdX, limU, limX);
+        static_for<0, DEPTH>([&](auto ic) {
+            load_clamped(ring[decltype(ic)::value], srdU, srdX, limU, limX, decltype(ic)::value);
+        });
+    }
+
+    const int nfull = n / DEPTH;
+    int done = 0;
+    if (nfull > 0) {
+        // first full block: slot i is followed by the rest of the prologue and by i steps
+        {
+            const rsrc_t rH = make_rsrc(start.stH), rC = make_rsrc(start.stC);
+            i32x4 srdU, srdX; unsigned limU, limX;
+            block_srds(DEPTH, srdU, srdX, limU, limX);
+            static_for<0, DEPTH>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                wait_slot<(DEPTH - 1 - i) * NLD + i * (NLD + NST)>(ring[i]);
+                step(slot_values(ring[i]), rH, rC, i);
+                load_clamped(ring[i], srdU, srdX, limU, limX, i);
+            });
+        }
+        // steady state (every row loaded is inside the range): slot i is followed by
+        // DEPTH-1 full steps
+        for (done = DEPTH; done + 2 * DEPTH <= n; done += DEPTH) {
+            const rsrc_t rH = make_rsrc(start.stH + (size_t)done * strideX);
+            const rsrc_t rC = make_rsrc(start.stC + (size_t)done * strideX);
+            const i32x4 srdU = make_srd(start.ldU + (size_t)(done + DEPTH) * strideU);
+            const i32x4 srdX = make_srd(start.ldX + (size_t)(done + DEPTH) * strideX);
+            static_for<0, DEPTH>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                wait_slot<(DEPTH - 1) * (NLD + NST)>(ring[i]);
+                step(slot_values(ring[i]), rH, rC, i);
+                issue_load(ring[i], srdU, srdX, offU, offX, (unsigned)i * strideU, (unsigned)i * strideX);
+            });
+        }
+        // last full block (if any is left): same counts, clamped rows
+        for (; done + DEPTH <= n; done += DEPTH) {
+            const rsrc_t rH = make_rsrc(start.stH + (size_t)done * strideX);
+            const rsrc_t rC = make_rsrc(start.stC + (size_t)done * strideX);
+            i32x4 srdU, srdX; unsigned limU, limX;
+            block_srds(done + DEPTH, srdU, srdX, limU, limX);
+            static_for<0, DEPTH>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                wait_slot<(DEPTH - 1) * (NLD + NST)>(ring[i]);
+                step(slot_values(ring[i]), rH, rC, i);
+                load_clamped(ring[i], srdU, srdX, limU, limX, i);
+            });
+        }
+    }
+    // last partial block (no loads): at least the rest of the previous block's (or the
+    // prologue's) loads follow slot i
+    {
+        const rsrc_t rH = make_rsrc(start.stH + (size_t)done * strideX);
+        const rsrc_t rC = make_rsrc(start.stC + (size_t)done * strideX);
+        static_for<0, DEPTH>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            wait_slot<(DEPTH - 1 - i) * NLD>(ring[i]);
+            if (done + i < n) step(slot_values(ring[i]), rH, rC, i);
+        });
+    }
+    p.ldU = start.ldU + (size_t)n * strideU;
+    p.ldX = start.ldX + (size_t)n * strideX;
+    if (STORE_H) p.stH = start.stH + (size_t)n * strideX;
+    if (STORE_C) p.stC = start.stC + (size_t)n * strideX;
+    return cur;
+}
+
+template <int K, int ACT, int DEPTH, bool STORE_C>
+__global__ void __launch_bounds__(WAVE)
+sru_fwd_cols(const float *__restrict__ U, const float *__restrict__ x,
+             const float *__restrict__ bias, const float *__restrict__ c0,
+             float *__restrict__ h, float *__restrict__ c_all, float *__restrict__ c_last,
+             int T_total, int ncols, int d, float scale_x, int h_t0,
+             int chunk_len, const float2 *__restrict__ carries)
+{
+    const int col = blockIdx.x * WAVE + threadIdx.x;
+    if (col >= ncols) return;
+    const int j = col % d;
+    const float bf2 = -LOG2E * bias[j], br2 = -LOG2E * bias[j + d];
+    float cur = c0 ? c0[col] : 0.0f;
+    const size_t nc = (size_t)ncols;
+    // time range of this workgroup: the whole sequence (gridDim.y == 1) or one chunk, whose
+    // incoming state is the composition of the preceding chunks' (A, B) aggregates
+    const int t_begin = blockIdx.y * chunk_len;
+    const int T = min(T_total, t_begin + chunk_len);
+    if (carries)
+        for (int cc = 0; cc < (int)blockIdx.y; ++cc) {
+            const float2 ab = carries[(size_t)cc * nc + col];
+            cur = __builtin_fmaf(ab.x, cur, ab.y);
+        }
+
+    if (T > t_begin) {
+        const unsigned strideU = (unsigned)(nc * K * sizeof(float)), strideX = (unsigned)(nc * sizeof(float));
+        const unsigned offU = (unsigned)col * K * sizeof(float), offX = (unsigned)col * sizeof(float);
+        ScanPtrs p;
+        p.ldU = reinterpret_cast<const char *>(U) + (size_t)t_begin * strideU;
+        p.ldX = reinterpret_cast<const char *>(x) + (size_t)t_begin * strideX;
+        p.stC = reinterpret_cast<char *>(c_all) + (size_t)t_begin * strideX;
+        // phase 1: steps before h_t0 produce no h (dmn.py:209 keeps the last H*W steps only)
+        const int t_mid = max(t_begin, min(h_t0, T));
+        p.stH = reinterpret_cast<char *>(h) + (size_t)(t_mid - h_t0) * strideX;
+        if (t_mid > t_begin)
+            cur = scan_range<K, ACT, DEPTH, STORE_C, false>(p, strideU, strideX, offU, offX,
+                                                            t_mid - t_begin, cur, bf2, br2, scale_x);
+        if (T > t_mid)
+            cur = scan_range<K, ACT, DEPTH, STORE_C, true>(p, strideU, strideX, offU, offX,
+                                                           T - t_mid, cur, bf2, br2, scale_x);
+    }
+    if (c_last && blockIdx.y == gridDim.y - 1) c_last[col] = cur;
+}
+
+template <int K, int ACT, bool STORE_C>
+static void launch_fwd(int depth, dim3 grid, hipStream_t s, const float *U, const float *x,
+                       const float *bias, const float *c0, float *h, float *c_all, float *c_last,
+                       int T, int ncols, int d, float scale_x, int h_t0, int chunk_len,
+                       const float2 *carries)
+{
+#define DMN_FWD(DEP)                                                                              \
+    hipLaunchKernelGGL((sru_fwd_cols<K, ACT, DEP, STORE_C>), grid, dim3(WAVE), 0, s, U, x, bias, \
+                       c0, h, c_all, c_last, T, ncols, d, scale_x, h_t0, chunk_len, carries)
+    if (depth <= 4) DMN_FWD(4);
+    else if (depth <= 8) DMN_FWD(8);
+    else if (depth <= 16) DMN_FWD(16);
+    else if (depth <= 24) DMN_FWD(24);
+    else DMN_FWD(32);
+#undef DMN_FWD
+}
+
+template <int K, bool STORE_C>
+static void launch_fwd_act(int act, int depth, dim3 grid, hipStream_t s, const float *U,
+                           const float *x, const float *bias, const float *c0, float *h,
+                           float *c_all, float *c_last, int T, int ncols, int d, float scale_x,
+                           int h_t0, int chunk_len, const float2 *carries)
+{
+    if (act == DMN_ACT_TANH)
+        launch_fwd<K, DMN_ACT_TANH, STORE_C>(depth, grid, s, U, x, bias, c0, h, c_all, c_last, T, ncols, d, scale_x, h_t0, chunk_len, carries);
+    else if (act == DMN_ACT_RELU)
+        launch_fwd<K, DMN_ACT_RELU, STORE_C>(depth, grid, s, U, x, bias, c0, h, c_all, c_last, T, ncols, d, scale_x, h_t0, chunk_len, carries);
+    else
+        launch_fwd<K, DMN_ACT_IDENTITY, STORE_C>(depth, grid, s, U, x, bias, c0, h, c_all, c_last, T, ncols, d, scale_x, h_t0, chunk_len, carries);
+}
+
+
+void DMN_SRU_LAUNCH_NAME(int act, bool store_c, int depth, dim3 grid, hipStream_t s, const float *U,
+                         const float *x, const float *bias, const float *c0, float *h,
+                         float *c_all, float *c_last, int T, int ncols, int d, float scale_x,
+                         int h_t0, int chunk_len, const float2 *carries)
+{
+    if (store_c) launch_fwd_act<DMN_SRU_K, true>(act, depth, grid, s, U, x, bias, c0, h, c_all, c_last, T, ncols, d, scale_x, h_t0, chunk_len, carries);
+    else         launch_fwd_act<DMN_SRU_K, false>(act, depth, grid, s, U, x, bias, c0, h, c_all, c_last, T, ncols, d, scale_x, h_t0, chunk_len, carries);
+}
+
+}  // namespace dmn

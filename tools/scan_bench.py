@@ -1,0 +1,64 @@
+#!/usr/bin/env python
+"""Microbench of the SRU scan entry points over shapes / prefetch depths / chunk counts."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from dms_amd import ops
+
+dev = "cuda"
+
+
+def run(T, B, d, k, h_t0, nch, depth, iters=10):
+    if depth:
+        os.environ["DMN_SRU_DEPTH"] = str(depth)
+    else:
+        os.environ.pop("DMN_SRU_DEPTH", None)
+    g = torch.Generator(device=dev).manual_seed(1)
+    u = torch.randn((T, B, d, k), device=dev, generator=g)
+    x = torch.randn((T, B, d), device=dev, generator=g) if k == 3 else None
+    bias = 0.1 * torch.randn((2 * d,), device=dev, generator=g)
+    for _ in range(2):
+        ops.sru_forward_raw(u, x, bias, None, "tanh", 1.0, h_t0, want_c=False, nchunks=nch)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        ops.sru_forward_raw(u, x, bias, None, "tanh", 1.0, h_t0, want_c=False, nchunks=nch)
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / iters
+    nbytes = (4 * k + (4 if k == 3 else 0)) * T * B * d + 4 * (T - h_t0) * B * d
+    print("T=%5d B=%3d d=%4d k=%d h_t0=%5d nch=%2d depth=%2s : %8.3f ms  %7.1f GB/s (%.1f%% of 8 TB/s)"
+          % (T, B, d, k, h_t0, nch, depth or "-", ms, nbytes / ms / 1e6, nbytes / ms / 1e6 / 80), flush=True)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("all", "insitu"):
+        for k in (4, 3):
+            for nch, depth in [(1, 8), (1, 16), (1, 24), (2, 8), (2, 16), (4, 8), (4, 16), (8, 8)]:
+                run(5120, 32, 1005, k, 0, nch, depth)
+        run(5120, 32, 1005, 3, 5120 - 256, 1, 24)
+    if which in ("all", "stress"):
+        for depth in (4, 8, 16, 24):
+            run(4096, 128, 1000, 3, 0, 1, depth)
+        run(4096, 128, 1005, 4, 0, 1, 8)
+        run(4096, 128, 1005, 4, 0, 1, 16)
+    if which == "deep":
+        for k in (4, 3):
+            for depth in (20, 24, 32, 40):
+                run(5120, 32, 1005, k, 0, 1, depth)
+        run(5120, 32, 1005, 3, 5120 - 256, 1, 32)
+        run(5120, 32, 1005, 3, 5120 - 256, 1, 40)
+        run(5120, 64, 1005, 4, 0, 1, 16)
+        run(5120, 64, 1005, 4, 0, 1, 24)
+        run(5120, 64, 1005, 4, 0, 1, 32)
+        run(5120, 16, 1005, 4, 0, 1, 40)
+        run(5120, 16, 1005, 4, 0, 2, 24)
+        run(5120, 8, 1005, 4, 0, 1, 40)
+        run(5120, 8, 1005, 4, 0, 4, 24)
+        run(5120, 8, 1005, 4, 0, 8, 16)
+    if which in ("all", "b1"):
+        for nch, depth in [(1, 24), (8, 8), (16, 8), (32, 8), (64, 8), (128, 8)]:
+            run(5120, 1, 1005, 4, 0, nch, depth)

@@ -1,0 +1,27 @@
+#!/usr/bin/env python
+"""Per-step kernel breakdown from a rocprofv3 --kernel-trace CSV of bench.py.
+Steady-state window = between the 3rd and the last dmn::cat_coords launch (one per forward)."""
+import csv
+import sys
+from collections import defaultdict
+
+path = sys.argv[1]
+topn = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+rows = list(csv.DictReader(open(path)))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+marks = [int(r["Start_Timestamp"]) for r in rows if "cat_coords" in r["Kernel_Name"]]
+lo, hi = marks[2], marks[-1]
+nsteps = len(marks) - 3
+agg = defaultdict(lambda: [0, 0.0])
+busy = 0.0
+for r in rows:
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    if lo <= s < hi:
+        a = agg[r["Kernel_Name"]]
+        a[0] += 1
+        a[1] += (e - s) / 1e6
+        busy += (e - s) / 1e6
+print("steady-state steps: %d ; wall per step %.2f ms ; kernel-busy per step %.2f ms"
+      % (nsteps, (hi - lo) / 1e6 / nsteps, busy / nsteps))
+for name, (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:topn]:
+    print("%8.3f ms/step %6.1f calls/step avg %9.1f us  %s" % (ms / nsteps, n / nsteps, ms / n * 1e3, name[:120]))
