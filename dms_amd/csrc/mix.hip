@@ -13,7 +13,7 @@
 
 namespace dmn {
 
-constexpr int MIX_PT = 4;      // pixels per workgroup
+constexpr int MIX_PT = 8;      // pixels per workgroup
 constexpr int MIX_KMAX = 16;   // filters kept in registers
 
 __device__ __forceinline__ long long lbk_off(int t, int b, int k, int B, int K, int ld)
@@ -21,7 +21,7 @@ __device__ __forceinline__ long long lbk_off(int t, int b, int k, int B, int K, 
     return ((long long)(t * B + b) * K + k) * ld;
 }
 
-template <int VEC, bool KREG>
+template <int VEC, int KR>    // KR > 0: the K <= KR filter weights of a lane stay in registers
 __global__ void __launch_bounds__(256)
 mix_fwd_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
                const float *__restrict__ P, const float *__restrict__ Wp, int ldw,
@@ -41,29 +41,40 @@ mix_fwd_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
     const int Mv = M / VEC;
     for (int mv = threadIdx.x; mv < Mv; mv += blockDim.x) {
         const int m = mv * VEC;
-        float w[VEC][KREG ? MIX_KMAX : 1];
+        constexpr bool KREG = KR > 0;
+        float w[VEC][KREG ? KR : 1];
         if (KREG) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e)
 #pragma unroll
-                for (int k = 0; k < MIX_KMAX; ++k)
+                for (int k = 0; k < KR; ++k)
                     w[e][k] = k < K ? Wp[(long long)(m + e) * ldw + k] : 0.0f;
         }
+        // A rows of the tile's pixels stay in registers; Bt[t] is loaded once per word and
+        // serves all MIX_PT pixels (MIX_PT independent 16-byte stores per load)
+        float a[MIX_PT][VEC];
+#pragma unroll
         for (int pp = 0; pp < MIX_PT; ++pp) {
-            const int s = s0 + pp;
-            if (s >= S) break;
-            float a[VEC];
+            const int s = s0 + pp < S ? s0 + pp : S - 1;
             const float *Ap = A + ((long long)b * S + s) * M + m;
-            if (VEC == 4) { const float4 v = *reinterpret_cast<const float4 *>(Ap); a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w; }
-            else a[0] = Ap[0];
-            for (int t = 0; t < L; ++t) {
+            if (VEC == 4) { const float4 v = *reinterpret_cast<const float4 *>(Ap); a[pp][0] = v.x; a[pp][1] = v.y; a[pp][2] = v.z; a[pp][3] = v.w; }
+            else a[pp][0] = Ap[0];
+        }
+#pragma unroll 2
+        for (int t = 0; t < L; ++t) {
+            float bt[VEC];
+            const float *Bp = Bt + ((long long)t * B + b) * M + m;
+            if (VEC == 4) { const float4 v = *reinterpret_cast<const float4 *>(Bp); bt[0] = v.x; bt[1] = v.y; bt[2] = v.z; bt[3] = v.w; }
+            else bt[0] = Bp[0];
+#pragma unroll
+            for (int pp = 0; pp < MIX_PT; ++pp) {
+                const int s = s0 + pp;
                 float q[VEC];
-                const float *Bp = Bt + ((long long)t * B + b) * M + m;
-                if (VEC == 4) { const float4 v = *reinterpret_cast<const float4 *>(Bp); q[0] = a[0] + v.x; q[1] = a[1] + v.y; q[2] = a[2] + v.z; q[3] = a[3] + v.w; }
-                else q[0] = a[0] + Bp[0];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) q[e] = a[pp][e] + bt[e];
                 if (KREG) {
 #pragma unroll
-                    for (int k = 0; k < MIX_KMAX; ++k) {
+                    for (int k = 0; k < KR; ++k) {
                         if (k < K) {
                             const float pv = Ps[(t * K + k) * MIX_PT + pp];
 #pragma unroll
@@ -78,9 +89,11 @@ mix_fwd_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
                             q[e] = __builtin_fmaf(Wp[(long long)(m + e) * ldw + k], pv, q[e]);
                     }
                 }
-                float *Qp = Q + (((long long)s * L + t) * B + b) * M + m;
-                if (VEC == 4) *reinterpret_cast<float4 *>(Qp) = make_float4(q[0], q[1], q[2], q[3]);
-                else Qp[0] = q[0];
+                if (s < S) {
+                    float *Qp = Q + (((long long)s * L + t) * B + b) * M + m;
+                    if (VEC == 4) *reinterpret_cast<float4 *>(Qp) = make_float4(q[0], q[1], q[2], q[3]);
+                    else Qp[0] = q[0];
+                }
             }
         }
     }
@@ -185,11 +198,17 @@ extern "C" int dmn_mix_bcast_add(const float *A, const float *Bt, const float *P
     dim3 grid((S + MIX_PT - 1) / MIX_PT, B);
     hipStream_t s = (hipStream_t)stream;
     const bool vec = (M % 4 == 0) && !(((uintptr_t)A | (uintptr_t)Bt | (uintptr_t)Q) & 15);
-    const bool kreg = K <= MIX_KMAX;
-    if (vec && kreg) hipLaunchKernelGGL((mix_fwd_kernel<4, true>), grid, dim3(256), lds, s, A, Bt, P, Wp, ldw, Q, B, L, K, S, M);
-    else if (vec)    hipLaunchKernelGGL((mix_fwd_kernel<4, false>), grid, dim3(256), lds, s, A, Bt, P, Wp, ldw, Q, B, L, K, S, M);
-    else if (kreg)   hipLaunchKernelGGL((mix_fwd_kernel<1, true>), grid, dim3(256), lds, s, A, Bt, P, Wp, ldw, Q, B, L, K, S, M);
-    else             hipLaunchKernelGGL((mix_fwd_kernel<1, false>), grid, dim3(256), lds, s, A, Bt, P, Wp, ldw, Q, B, L, K, S, M);
+#define DMN_MIX(V, KR) hipLaunchKernelGGL((mix_fwd_kernel<V, KR>), grid, dim3(256), lds, s, A, Bt, P, Wp, ldw, Q, B, L, K, S, M)
+    if (vec) {
+        if (K <= 4) DMN_MIX(4, 4);
+        else if (K <= 10) DMN_MIX(4, 10);
+        else if (K <= MIX_KMAX) DMN_MIX(4, MIX_KMAX);
+        else DMN_MIX(4, 0);
+    } else {
+        if (K <= MIX_KMAX) DMN_MIX(1, MIX_KMAX);
+        else DMN_MIX(1, 0);
+    }
+#undef DMN_MIX
     return launch_status("dmn_mix_bcast_add");
 }
 

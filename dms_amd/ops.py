@@ -38,12 +38,17 @@ def _ptr(t):
 # SRU scan
 # ------------------------------------------------------------------------------------
 def sru_scan_chunks(T, ncols):
-    """How many time chunks the time-parallel variant should use (1 = plain column scan)."""
+    """How many time chunks the time-parallel variant should use (1 = plain column scan).
+
+    Measured on MI355X (tools/scan_bench.py, T=5120, d=1005): from ~126 wavefronts (B=8) up
+    the plain column scan wins (each wave already owns a SIMD and the chunked variant reads U
+    twice); below that, ~512 wavefront-chunks in flight is the sweet spot (B=1: 291 us plain
+    vs 39 us with 32 chunks).
+    """
     waves = (ncols + 63) // 64
-    if waves >= 512 or T < 512:
+    if waves >= 100 or T < 128:
         return 1
-    n = min(max(2048 // waves, 1), T // 64)
-    return max(n, 1)
+    return max(min(512 // waves, T // 64), 1)
 
 
 def sru_forward_raw(u, x, bias, c0, act, scale_x, h_t0=0, want_c=False, nchunks=None):

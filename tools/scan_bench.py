@@ -59,6 +59,12 @@ if __name__ == "__main__":
         run(5120, 8, 1005, 4, 0, 1, 40)
         run(5120, 8, 1005, 4, 0, 4, 24)
         run(5120, 8, 1005, 4, 0, 8, 16)
+    if which == "small":
+        for B in (1, 2, 4, 8):
+            for nch, depth in [(1, 32), (4, 8), (8, 8), (16, 8), (32, 8), (64, 8)]:
+                run(5120, B, 1005, 4, 0, nch, depth)
+        for nch, depth in [(1, 32), (8, 8), (32, 8), (64, 8)]:
+            run(2000, 1, 1005, 3, 1900, nch, depth)
     if which in ("all", "b1"):
         for nch, depth in [(1, 24), (8, 8), (16, 8), (32, 8), (64, 8), (128, 8)]:
             run(5120, 1, 1005, 4, 0, nch, depth)
