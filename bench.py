@@ -105,6 +105,17 @@ class LaunchTimer(object):
         return out
 
 
+def measured_traffic(kernel_label):
+    """HBM bytes per launch from the committed PMC passes (profiles/traffic_r1.json; separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 FETCH x2 correction) or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic_r1.json")) as f:
+            table = json.load(f)
+        return table[kernel_label]["hbm_bytes"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def build_model(device, high_res=True):
     import dms_amd
     torch.manual_seed(SEED)
@@ -210,7 +221,8 @@ def main():
                 "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": "msru_stress T=4096 B=128 d=1000 k=3 (BASELINE configs[4])"},
                 "roofline": {"bound": "hbm", "achieved": row["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": row["frac_of_8TBs"], "traffic": None,
+                             "unit": "GB/s", "frac": row["frac_of_8TBs"],
+                             "traffic": measured_traffic(row["kernel"]),
                              "kernel": row["kernel"], "avg_launch_ms": row["avg_ms"]}}
         if rank == 0:
             print(json.dumps(line))
@@ -248,7 +260,7 @@ def main():
     scans = [r for r in kernels if r["kernel"].startswith("sru_fwd") and "T=%d" % (256 * 20) in r["kernel"]]
     dom = scans[0] if scans else kernels[0]
     roofline = {"bound": "hbm", "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": dom["frac_of_8TBs"], "traffic": None,
+                "unit": "GB/s", "frac": dom["frac_of_8TBs"], "traffic": measured_traffic(dom["kernel"]),
                 "kernel": dom["kernel"], "avg_launch_ms": dom["avg_ms"],
                 "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"]}
     hip_ms = sum(r["total_ms"] for r in kernels) / args.steps
