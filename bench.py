@@ -71,6 +71,19 @@ class LaunchTimer(object):
             label = "sru_fwd k=%d T=%d cols=%d%s%s" % (
                 k, T, B * d, " tail" if h_t0 else "", " scan" if name.endswith("scan") else "")
             return label, rd + wr
+        if name == "dmn_sru_bwd":
+            T, B, d, k = args[11:15]
+            per = (4 * k + (4 if k == 3 else 0) + 8) + (4 * k + (4 if k == 3 else 0))
+            return "sru_bwd k=%d T=%d cols=%d" % (k, T, B * d), per * T * B * d
+        if name == "dmn_dynfilter_bwd":
+            B, L, K, C, S = args[5:10]
+            return "dynfilter_bwd", 4 * B * (2 * C * S + 2 * L * K * C + 2 * L * K * S)
+        if name == "dmn_mix_bcast_add_bwd":
+            B, L, K, S, M = args[8:13]
+            return "mix_bcast_add_bwd", 4 * B * (2 * S * L * M + S * M + L * M + 2 * L * K * S + L * M * K)
+        if name == "dmn_cat_upsample2x_bwd":
+            B, Cx, Cf, H, W = args[3:8]
+            return "cat_upsample2x_bwd %dx%d" % (H, W), 4 * B * (Cx + Cf) * H * W * 5
         if name == "dmn_dynfilter_fwd":
             B, L, K, C, S = args[3:8]
             return "dynfilter_fwd", 4 * B * (C * S + L * K * C + L * K * S)
@@ -157,6 +170,81 @@ def cpu_baseline_dmn(net, reps, threads):
             "seconds_per_query": round(med, 3)}, (img, words, out)
 
 
+def run_train320(args, device, rank, world, timer):
+    """BASELINE configs[3]: low-res 320 px training step, batch 64 per GPU: forward -> bilinear
+    upsample of the logits to the mask size -> BCEWithLogits vs random {0,1} masks
+    (train.py:275-283) -> backward -> gradient all-reduce (RCCL) -> Adam(lr 1e-5) (train.py:71,242)."""
+    import torch.nn.functional as F
+    from dms_amd.dist import allreduce_gradients
+    net = build_model(device, high_res=False).train()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-5)
+    B = args.batch
+    g = torch.Generator(device=device).manual_seed(SEED + rank)
+    img = torch.randn((B, 3, 320, 320), device=device, generator=g)
+    words = torch.randint(0, 1000, (B, 20), device=device, generator=g)
+    mask = (torch.rand((B, 1, 320, 320), device=device, generator=g) > 0.5).float()
+    crit = torch.nn.BCEWithLogitsLoss()
+    ar_ms = []
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = net(img, words)
+        out = F.interpolate(out, size=mask.shape[-2:], mode="bilinear", align_corners=False)
+        loss = crit(out, mask)
+        loss.backward()
+        if world > 1:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            allreduce_gradients(list(net.parameters()), bucket_mb=256, average=True)
+            b.record()
+            ar_ms.append((a, b))
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    timer.records, ar_ms[:] = [], []
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    assert bool(torch.isfinite(loss))
+    el = torch.tensor([elapsed], dtype=torch.float64,
+                      device=device if dist.is_initialized() and dist.get_backend() == "nccl" else "cpu")
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    kernels = timer.summary()
+    bw = [r for r in kernels if r["kernel"].startswith("sru_bwd") and "T=2000" in r["kernel"]]
+    dom = bw[0] if bw else kernels[0]
+    nparams = sum(p.numel() for p in net.parameters())
+    line = {"metric": "training samples/sec (whole node), DMN low-res 320px step; mSRU bwd achieved HBM GB/s",
+            "value": round(world * B * args.steps / elapsed, 3), "unit": "samples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "DMN low-res 320px training step (BASELINE configs[3]): BCEWithLogits, "
+                                   "Adam lr 1e-5, train() mode", "batch_per_gpu": B,
+                       "global_batch": B * world, "grad_allreduce_MB": round(nparams * 4 / 1e6, 1),
+                       "parallelism": "data parallel, one bucketed fp32 all-reduce per step"},
+            "roofline": {"bound": "hbm", "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": dom["frac_of_8TBs"], "traffic": None,
+                         "kernel": dom["kernel"], "avg_launch_ms": dom["avg_ms"]},
+            "allreduce_ms": round(sum(a.elapsed_time(b) for a, b in ar_ms) / max(len(ar_ms), 1), 3) if ar_ms else None,
+            "hip_kernels_ms_per_step": round(sum(r["total_ms"] for r in kernels) / args.steps, 3),
+            "hip_kernels": kernels, "loss": float(loss)}
+    if rank == 0:
+        print(json.dumps(line))
+
+
 def run_msru_stress(device, steps, warmup, timer):
     """BASELINE.json configs[4]: standalone scan, T = 64*64, hidden 1000, batch 128, k = 3."""
     from dms_amd import ops
@@ -185,11 +273,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="(image, query) pairs per GPU")
-    ap.add_argument("--workload", default="dmn512", choices=["dmn512", "msru_stress"])
+    ap.add_argument("--batch", type=int, default=None,
+                    help="(image, query) pairs per GPU (default 32; 64 for train320)")
+    ap.add_argument("--workload", default="dmn512", choices=["dmn512", "msru_stress", "train320"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=5)
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 64 if args.workload == "train320" else 32
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -198,11 +289,18 @@ def main():
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # rehearsal hooks (one-GPU box): DMN_BENCH_DEVICE pins every rank to one card and
+    # DMN_BENCH_BACKEND=gloo replaces RCCL, which refuses two ranks on the same device
+    dev_index = int(os.environ.get("DMN_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("DMN_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from dms_amd import _lib
     _lib.load()
@@ -212,6 +310,12 @@ def main():
     def barrier():
         if world > 1:
             dist.barrier()
+
+    if args.workload == "train320":
+        run_train320(args, device, rank, world, timer)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     if args.workload == "msru_stress":
         row, ms = run_msru_stress(device, args.steps, args.warmup, timer)
@@ -250,7 +354,7 @@ def main():
         timer.enabled = False
     assert tuple(out.shape) == (B, 1, 512, 512) and bool(torch.isfinite(out).all())
 
-    el = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())

@@ -100,79 +100,136 @@ mix_fwd_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
 }
 
 // ---- backward A: per (b, pixel): gA[b,s,m] = sum_t gQ ; gP[t,b,k,s] = sum_m Wp[m,k] gQ ----
+// One 256-thread workgroup per (b, tile of MIX_BWD_PT pixels).  Wp is staged once per
+// workgroup into LDS, transposed to [k][M] so that a lane's 4 adjacent m are one ds_read_b128.
+// Wave w owns the words t = w, w+4, ...: its 64 lanes sweep the M-long gQ row in 16-byte
+// pieces (lane-private partial dot products with the K filter columns), then ONE butterfly
+// reduction per (t, k) inside the wave (no workgroup barrier per word).  gA is accumulated per
+// lane and combined across the 4 waves through LDS.  Requires M % 4 == 0, M <= 1024.
+constexpr int MIX_BWD_PT = 4;
+
 __global__ void __launch_bounds__(256)
 mix_bwd_pix_kernel(const float *__restrict__ gQ, const float *__restrict__ Wp, int ldw,
                    float *__restrict__ gA, float *__restrict__ gP, int B, int L, int K, int S, int M)
 {
-    __shared__ float red[4][MIX_KMAX];
-    const int b = blockIdx.y, s = blockIdx.x;
+    extern __shared__ float lds[];                  // Wl[K][M] then ga_lds[4][M]
+    float *Wl = lds, *ga_lds = lds + (size_t)K * M;
+    const int b = blockIdx.y, s0 = blockIdx.x * MIX_BWD_PT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // lane-private accumulators for up to 4 strided m (M <= 1024)
-    float ga[4] = {0, 0, 0, 0};
-    for (int t = 0; t < L; ++t) {
-        float part[MIX_KMAX];
+    for (int idx = threadIdx.x; idx < K * M; idx += blockDim.x) {
+        const int m = idx / K, k = idx - m * K;
+        Wl[k * M + m] = Wp[(long long)m * ldw + k];
+    }
+    __syncthreads();
+    for (int pp = 0; pp < MIX_BWD_PT; ++pp) {
+        const int s = s0 + pp;
+        if (s >= S) break;                          // uniform
+        float ga[16];
 #pragma unroll
-        for (int k = 0; k < MIX_KMAX; ++k) part[k] = 0.0f;
-        const float *g = gQ + (((long long)s * L + t) * B + b) * M;
+        for (int i = 0; i < 16; ++i) ga[i] = 0.0f;
+        for (int t = wave; t < L; t += 4) {
+            float part[MIX_KMAX];
+#pragma unroll
+            for (int k = 0; k < MIX_KMAX; ++k) part[k] = 0.0f;
+            const float *g = gQ + (((long long)s * L + t) * B + b) * M;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = (i * 64 + lane) * 4;
+                if (m < M) {
+                    const float4 gv = *reinterpret_cast<const float4 *>(g + m);
+                    ga[i * 4 + 0] += gv.x; ga[i * 4 + 1] += gv.y; ga[i * 4 + 2] += gv.z; ga[i * 4 + 3] += gv.w;
+#pragma unroll
+                    for (int k = 0; k < MIX_KMAX; ++k) {
+                        if (k < K) {
+                            const float4 w = *reinterpret_cast<const float4 *>(Wl + k * M + m);
+                            part[k] = __builtin_fmaf(w.x, gv.x, part[k]);
+                            part[k] = __builtin_fmaf(w.y, gv.y, part[k]);
+                            part[k] = __builtin_fmaf(w.z, gv.z, part[k]);
+                            part[k] = __builtin_fmaf(w.w, gv.w, part[k]);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < MIX_KMAX; ++k) {
+                if (k < K) {
+                    float v = part[k];
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                    if (lane == 0) gP[lbk_off(t, b, k, B, K, S) + s] = v;
+                }
+            }
+        }
+        // combine the 4 waves' gA partials
+        __syncthreads();                            // previous pixel's ga_lds readers are done
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int m = threadIdx.x + i * 256;
-            if (m < M) {
-                const float gv = g[m];
-                ga[i] += gv;
-#pragma unroll
-                for (int k = 0; k < MIX_KMAX; ++k)
-                    if (k < K) part[k] = __builtin_fmaf(Wp[(long long)m * ldw + k], gv, part[k]);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < MIX_KMAX; ++k) {
-            if (k < K) {
-                float v = part[k];
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-                if (lane == 0) red[wave][k] = v;
-            }
+            const int m = (i * 64 + lane) * 4;
+            if (m < M)
+                *reinterpret_cast<float4 *>(ga_lds + wave * M + m) =
+                    make_float4(ga[i * 4], ga[i * 4 + 1], ga[i * 4 + 2], ga[i * 4 + 3]);
         }
         __syncthreads();
-        if (threadIdx.x < K)
-            gP[lbk_off(t, b, threadIdx.x, B, K, S) + s] =
-                red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        __syncthreads();
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = threadIdx.x + i * 256;
-        if (m < M) gA[((long long)b * S + s) * M + m] = ga[i];
+        for (int m = threadIdx.x; m < M; m += 256)
+            gA[((long long)b * S + s) * M + m] =
+                ga_lds[m] + ga_lds[M + m] + ga_lds[2 * M + m] + ga_lds[3 * M + m];
     }
 }
 
 // ---- backward B: per (t, b): gBt[t,b,m] = sum_s gQ ; gWp_part[t,b,m,k] = sum_s gQ * P ----
+// One workgroup per (t, b); a lane owns 4 adjacent m (16-byte loads), the pixel loop is
+// unrolled so that 4 independent rows are in flight per lane; P[t,b] (K x S) sits in LDS.
+template <int VEC>
 __global__ void __launch_bounds__(256)
 mix_bwd_word_kernel(const float *__restrict__ gQ, const float *__restrict__ P,
                     float *__restrict__ gBt, float *__restrict__ gWp_part,
                     int B, int L, int K, int S, int M)
 {
-    extern __shared__ float Pt[];            // [K][S] for this (t, b)
+    extern __shared__ float Pt[];            // [S][K] for this (t, b) (k innermost)
     const int t = blockIdx.x, b = blockIdx.y;
-    for (int idx = threadIdx.x; idx < K * S; idx += blockDim.x)
-        Pt[idx] = P[lbk_off(t, b, 0, B, K, S) + idx];
+    for (int idx = threadIdx.x; idx < K * S; idx += blockDim.x) {
+        const int k = idx / S, sp = idx - k * S;
+        Pt[sp * K + k] = P[lbk_off(t, b, 0, B, K, S) + idx];
+    }
     __syncthreads();
-    for (int m = threadIdx.x; m < M; m += blockDim.x) {
-        float gb = 0.0f, gw[MIX_KMAX];
+    const long long row_stride = (long long)L * B * M;     // between consecutive pixels
+    for (int mv = threadIdx.x; mv < M / VEC; mv += blockDim.x) {
+        const int m = mv * VEC;
+        float gb[VEC], gw[VEC][MIX_KMAX];
 #pragma unroll
-        for (int k = 0; k < MIX_KMAX; ++k) gw[k] = 0.0f;
-        for (int s = 0; s < S; ++s) {
-            const float gv = gQ[(((long long)s * L + t) * B + b) * M + m];
-            gb += gv;
+        for (int e = 0; e < VEC; ++e) {
+            gb[e] = 0.0f;
+#pragma unroll
+            for (int k = 0; k < MIX_KMAX; ++k) gw[e][k] = 0.0f;
+        }
+        const float *g0 = gQ + ((long long)t * B + b) * M + m;
+#pragma unroll 4
+        for (int sp = 0; sp < S; ++sp) {
+            float ge[VEC];
+            if (VEC == 4) {
+                const float4 gv = *reinterpret_cast<const float4 *>(g0 + sp * row_stride);
+                ge[0] = gv.x; ge[1] = gv.y; ge[2] = gv.z; ge[VEC - 1] = gv.w;
+            } else {
+                ge[0] = g0[sp * row_stride];
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) gb[e] += ge[e];
+#pragma unroll
+            for (int k = 0; k < MIX_KMAX; ++k) {
+                if (k < K) {
+                    const float pv = Pt[sp * K + k];
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) gw[e][k] = __builtin_fmaf(ge[e], pv, gw[e][k]);
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            gBt[((long long)t * B + b) * M + m + e] = gb[e];
 #pragma unroll
             for (int k = 0; k < MIX_KMAX; ++k)
-                if (k < K) gw[k] = __builtin_fmaf(gv, Pt[k * S + s], gw[k]);
+                if (k < K) gWp_part[(((long long)t * B + b) * M + m + e) * K + k] = gw[e][k];
         }
-        gBt[((long long)t * B + b) * M + m] = gb;
-#pragma unroll
-        for (int k = 0; k < MIX_KMAX; ++k)
-            if (k < K) gWp_part[(((long long)t * B + b) * M + m) * K + k] = gw[k];
     }
 }
 
@@ -224,7 +281,12 @@ extern "C" int dmn_mix_bcast_add_bwd(const float *gQ, const float *P, const floa
     const size_t lds = (size_t)K * S * sizeof(float);
     if (lds > 64 * 1024) return fail(-5, "dmn_mix_bcast_add_bwd: K*S=%d too large for the LDS stage", K * S);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(mix_bwd_pix_kernel, dim3(S, B), dim3(256), 0, s, gQ, Wp, ldw, gA, gP, B, L, K, S, M);
-    hipLaunchKernelGGL(mix_bwd_word_kernel, dim3(L, B), dim3(256), lds, s, gQ, P, gBt, gWp_part, B, L, K, S, M);
+    if (M % 4 != 0 || ((uintptr_t)gQ & 15)) return fail(-5, "dmn_mix_bcast_add_bwd: M %% 4 == 0 and 16-byte aligned gQ required");
+    const size_t lds_pix = (size_t)(K + 4) * M * sizeof(float);
+    hipLaunchKernelGGL(mix_bwd_pix_kernel, dim3((S + MIX_BWD_PT - 1) / MIX_BWD_PT, B), dim3(256), lds_pix, s, gQ, Wp, ldw, gA, gP, B, L, K, S, M);
+    if ((M % 4 == 0) && !((uintptr_t)gQ & 15))
+        hipLaunchKernelGGL(mix_bwd_word_kernel<4>, dim3(L, B), dim3(256), lds, s, gQ, P, gBt, gWp_part, B, L, K, S, M);
+    else
+        hipLaunchKernelGGL(mix_bwd_word_kernel<1>, dim3(L, B), dim3(256), lds, s, gQ, P, gBt, gWp_part, B, L, K, S, M);
     return launch_status("dmn_mix_bcast_add_bwd");
 }

@@ -118,7 +118,7 @@ int dmn_mix_bcast_add(const float *A, const float *Bt, const float *P, const flo
  * gradients of dmn_mix_bcast_add w.r.t. A, Bt, P, Wp given gQ (S*L, B, M):
  *   gA[b,s,m] = sum_t gQ ; gBt[t,b,m] = sum_s gQ ; gP[t,b,k,s] = sum_m Wp[m,k] gQ ;
  *   gWp_part (L, B, M, K) partial sums per (word, batch entry) (caller reduces over L, B).
- *   Limits: K <= 16, M <= 1024.
+ *   Limits: K <= 16, M <= 1024, M % 4 == 0.
  */
 int dmn_mix_bcast_add_bwd(const float *gQ, const float *P, const float *Wp, int ldw,
                           float *gA, float *gBt, float *gP, float *gWp_part,
