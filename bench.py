@@ -193,6 +193,9 @@ def run_train320(args, device, rank, world, timer):
         loss = crit(out, mask)
         loss.backward()
         if world > 1:
+            if os.environ.get("DMN_BENCH_VERBOSE"):
+                torch.cuda.synchronize()
+                print("[train320] rank %d backward done, all-reduce..." % rank, file=sys.stderr, flush=True)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             allreduce_gradients(list(net.parameters()), bucket_mb=256, average=True)
@@ -201,9 +204,10 @@ def run_train320(args, device, rank, world, timer):
         opt.step()
         return loss
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         loss = step()
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        print("[train320] rank %d warm-up step %d done" % (rank, i), file=sys.stderr, flush=True)
     if world > 1:
         dist.barrier()
     timer.records, ar_ms[:] = [], []

@@ -28,7 +28,9 @@ mix_fwd_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
                float *__restrict__ Q, int B, int L, int K, int S, int M)
 {
     extern __shared__ float Ps[];            // [L*K][MIX_PT]
-    const int b = blockIdx.y, s0 = blockIdx.x * MIX_PT;
+    // launch order = (piece, b) fastest, pixel tile slowest: workgroups that run together
+    // write the same contiguous (s,t) slabs of Q (B*M*4 bytes each) -> DRAM page locality
+    const int b = blockIdx.y, s0 = blockIdx.z * MIX_PT;
     const int LK = L * K;
     for (int idx = threadIdx.x; idx < LK * MIX_PT; idx += blockDim.x) {
         const int r = idx / MIX_PT, pp = idx - r * MIX_PT;
@@ -39,7 +41,9 @@ mix_fwd_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
     __syncthreads();
 
     const int Mv = M / VEC;
-    for (int mv = threadIdx.x; mv < Mv; mv += blockDim.x) {
+    // blockIdx.x walks the row in pieces of 256 lanes (M = 1000: one piece; the folded
+    // layer-0 projection has M = 4020: four), so the grid grows instead of a per-lane loop
+    for (int mv = blockIdx.x * blockDim.x + threadIdx.x; mv < Mv; mv += gridDim.x * blockDim.x) {
         const int m = mv * VEC;
         constexpr bool KREG = KR > 0;
         float w[VEC][KREG ? KR : 1];
@@ -252,9 +256,11 @@ extern "C" int dmn_mix_bcast_add(const float *A, const float *Bt, const float *P
     if (int rc = check_mix("dmn_mix_bcast_add", B, L, K, S, M, ldw)) return rc;
     const size_t lds = (size_t)L * K * MIX_PT * sizeof(float);
     if (lds > 64 * 1024) return fail(-5, "dmn_mix_bcast_add: L*K=%d too large for the LDS stage", L * K);
-    dim3 grid((S + MIX_PT - 1) / MIX_PT, B);
     hipStream_t s = (hipStream_t)stream;
     const bool vec = (M % 4 == 0) && !(((uintptr_t)A | (uintptr_t)Bt | (uintptr_t)Q) & 15);
+    const int pieces = ((vec ? M / 4 : M) + 255) / 256;
+    if ((S + MIX_PT - 1) / MIX_PT > 65535) return fail(-5, "dmn_mix_bcast_add: S=%d too large", S);
+    dim3 grid(pieces, B, (S + MIX_PT - 1) / MIX_PT);
 #define DMN_MIX(V, KR) hipLaunchKernelGGL((mix_fwd_kernel<V, KR>), grid, dim3(256), lds, s, A, Bt, P, Wp, ldw, Q, B, L, K, S, M)
     if (vec) {
         if (K <= 4) DMN_MIX(4, 4);

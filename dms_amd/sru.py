@@ -42,6 +42,16 @@ class SRUCell(nn.Module):
         with torch.no_grad():
             self.bias[self.n_out:].fill_(bias_val)
 
+    def forward_projected(self, u, c0=None, h_t0=0):
+        """Scan on an already projected input ``u (len, B, n_out, 4)`` (k = 4 cells only: the
+        highway term is U[..., 3], so the raw input is not needed).  Used when the caller has
+        folded this cell's x.W into an upstream linear map."""
+        if self.k != 4:
+            raise ValueError("forward_projected needs a k = 4 cell (n_in != n_out)")
+        T, B = u.shape[0], u.shape[1]
+        return ops.sru_compute(u.reshape(T, B, self.n_out, 4), None, self.bias, c0,
+                               self.activation, self.scale_x, h_t0)
+
     def forward(self, input, c0=None, h_t0=0):
         if input.dim() != 3:
             raise ValueError("SRUCell expects (len, batch, n_in), got %s" % (tuple(input.shape),))
@@ -71,9 +81,11 @@ class SRU(nn.Module):
         for cell in self.rnn_lst:
             cell.set_bias(bias_val)
 
-    def forward(self, input, c0=None, return_hidden=True, tail=None):
+    def forward(self, input, c0=None, return_hidden=True, tail=None, projected=False):
         """``tail=n`` (extension): only the last n steps of the LAST layer's h are produced
-        (what dmn.py:209 keeps), so the final scan stores S instead of S*L rows."""
+        (what dmn.py:209 keeps), so the final scan stores S instead of S*L rows.
+        ``projected=True`` (extension): ``input`` is already layer 0's U = x.W,
+        shape (len, B, hidden*4); layer 0 must be a k = 4 cell."""
         if input.dim() != 3:
             raise ValueError("SRU expects (len, batch, n_in), got %s" % (tuple(input.shape),))
         T = input.shape[0]
@@ -82,7 +94,10 @@ class SRU(nn.Module):
         for i, cell in enumerate(self.rnn_lst):
             last = i == self.depth - 1
             h_t0 = max(T - int(tail), 0) if (last and tail is not None) else 0
-            prev, c = cell(prev, c0s[i], h_t0)
+            if i == 0 and projected:
+                prev, c = cell.forward_projected(prev, c0s[i], h_t0)
+            else:
+                prev, c = cell(prev, c0s[i], h_t0)
             lst.append(c)
         if return_hidden:
             return prev, torch.stack(lst)

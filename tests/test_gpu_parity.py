@@ -266,6 +266,24 @@ def test_hot_path_matches_reference_golden(name):
         assert agree >= 0.999
 
 
+def test_folded_layer0_projection_equals_unfused_path():
+    """comb_conv folded into the mSRU layer-0 projection (inference) vs the unfused path."""
+    net, vis, lang, g, cfg, _ = _product_base("base_full_320_lowres")
+    with torch.no_grad():
+        assert net.fold_comb_into_msru and net.mrnn.rnn_lst[0].k == 4
+        a = net.hot_path(vis.to(DEV), lang.to(DEV)).cpu()
+        net.fold_comb_into_msru = False
+        b = net.hot_path(vis.to(DEV), lang.to(DEV)).cpu()
+        # cache follows in-place weight updates
+        net.fold_comb_into_msru = True
+        net.comb_conv.weight.mul_(0.5)
+        c = net.hot_path(vis.to(DEV), lang.to(DEV)).cpu()
+        net.fold_comb_into_msru = False
+        d = net.hot_path(vis.to(DEV), lang.to(DEV)).cpu()
+    assert rel_err(a, b) < 2e-5 and rel_err(a, g["out"]) < 1e-4 and rel_err(b, g["out"]) < 1e-4
+    assert rel_err(c, d) < 2e-5 and rel_err(c, a) > 1e-3
+
+
 def test_hot_path_batched_equals_independent_batch1_forwards():
     net, vis, lang, g, cfg, state = _product_base("base_tiny_k4")
     B = 3
