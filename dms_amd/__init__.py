@@ -7,8 +7,11 @@ dmn_pytorch/models/__init__.py:11) plus the SRU modules that replace the third-p
 """
 from .models import DMN, BaseDMN, UpsamplingModule
 from .sru import SRU, SRUCell
+from .text import Corpus, Dictionary
+from .metrics import SegmentationEvaluator, threshold_iou
 
 VERSION_INFO = (0, 1, 0)
 __version__ = ".".join(map(str, VERSION_INFO))
 
-__all__ = ["DMN", "BaseDMN", "UpsamplingModule", "SRU", "SRUCell"]
+__all__ = ["DMN", "BaseDMN", "UpsamplingModule", "SRU", "SRUCell", "Corpus", "Dictionary",
+           "SegmentationEvaluator", "threshold_iou"]

@@ -29,6 +29,7 @@ SIGNATURES = {
     "dmn_mix_bcast_add_bwd": [_p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "dmn_cat_upsample2x": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
     "dmn_cat_upsample2x_bwd": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "dmn_threshold_iou": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
 }
 
 _lib = None

@@ -138,6 +138,18 @@ int dmn_cat_upsample2x(const float *x, const float *feat, float *out,
 int dmn_cat_upsample2x_bwd(const float *g, float *gx, float *gfeat,
                            int B, int Cx, int Cf, int H, int W, void *stream);
 
+/*
+ * Evaluation threshold sweep.  Replaces, per sample, the loop
+ * `for thresh in score_thresh: compute_mask_IU((out > thresh).float(), mask)`
+ * (dmn_pytorch/train.py:333-338 and 366-374) by one pass over the pixels.
+ *   prob (B, N) probabilities (sigmoid + upsample done by the caller, train.py:361-364)
+ *   mask (B, N) target (0/1);  thresholds (NT) ASCENDING, NT <= 64 (device memory)
+ *   inter, uni (B, NT): ACCUMULATED INTO (zero them first):
+ *     inter[b,j] += sum((prob > th_j) * mask) ; uni[b,j] += sum((prob > th_j) + mask - (prob > th_j) * mask)
+ */
+int dmn_threshold_iou(const float *prob, const float *mask, const float *thresholds,
+                      float *inter, float *uni, int B, int N, int NT, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -189,5 +189,62 @@ def main():
     print("dmn_e2e_64px_highres", tuple(y.shape), float(y.std()), len(sd))
 
 
+def gen_text_and_eval():
+    """word_utils.Corpus (pure python + torch: imported as is) and train.py's
+    compute_mask_IU (train.py executes argparse + dataset loading at import, so only that
+    function's source is compiled, via ast) -> tests/golden/{tokenize,eval_iou}.json/.npz"""
+    import ast
+    import json
+    import importlib.util
+    # loaded by path: dmn_pytorch/utils/__init__.py would import transforms -> cv2 (absent)
+    spec = importlib.util.spec_from_file_location(
+        "ref_word_utils", os.path.join(REF, "dmn_pytorch", "utils", "word_utils.py"))
+    wu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(wu)
+    vocab_lines = ["The left horse", "man in a red shirt standing", "second zebra from the right .",
+                   "Bottle", "a CAT on the couch, sleeping", "person's hand", "giraffe"]
+    queries = ["the left horse", "The man in the RED shirt.", "zebra, second from right .",
+               "an unknown-word here", "  padded   spaces  ", "horse .", "cat",
+               "a a a a a a a a a a a a a a a a a a a a a a a a the end", "person's hand!"]
+    c = wu.Corpus()
+    for l in vocab_lines:
+        c.add_to_corpus(l)
+    c.dictionary.add_word(wu.UNK_TOKEN)
+    c.dictionary.add_word(wu.PAD_TOKEN)
+    rec = {"vocab_lines": vocab_lines, "queries": queries, "idx2word": c.dictionary.idx2word,
+           "ids_20": [c.tokenize(q, 20).tolist() for q in queries],
+           "ids_5": [c.tokenize(q, 5).tolist() for q in queries],
+           "ids_nolimit": [c.tokenize(q, -1).tolist() for q in queries]}
+    with open(os.path.join(OUT, "tokenize.json"), "w") as f:
+        json.dump(rec, f, indent=1)
+    print("tokenize.json", len(queries), "queries, vocab", len(c))
+
+    src = open(os.path.join(REF, "dmn_pytorch", "train.py")).read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "compute_mask_IU"][0]
+    ns = {}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "train.py:compute_mask_IU", "exec"), ns)
+    compute_mask_IU = ns["compute_mask_IU"]
+    # the threshold sweep of evaluate(), train.py:343-374, on deterministic inputs
+    score_thresh = np.concatenate([np.arange(start=0.00, stop=0.96, step=0.025)]).tolist()
+    N, Hh, Ww = 3, 37, 29
+    prob = torch.sigmoid(det_uniform((N, Hh, Ww), 501, 4.0))
+    prob[0, 0, :5] = torch.tensor(score_thresh[10:15], dtype=torch.float32)     # exact ties
+    mask = (det_uniform((N, Hh, Ww), 502, 1.0) > 0.2).float()
+    mask[2] = 0                                                               # empty target
+    inter = torch.zeros(N, len(score_thresh))
+    union = torch.zeros(N, len(score_thresh))
+    for n in range(N):
+        for idx, thresh in enumerate(score_thresh):
+            inter[n, idx], union[n, idx] = compute_mask_IU((prob[n] > thresh).float(), mask[n])
+    np.savez_compressed(os.path.join(OUT, "eval_iou.npz"), inter=inter.numpy(), union=union.numpy(),
+                        thresholds=np.array(score_thresh, dtype=np.float64), N=N, H=Hh, W=Ww)
+    print("eval_iou.npz", inter.shape, float(inter.sum()), float(union.sum()))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "extras":
+        import_reference()
+        gen_text_and_eval()
+    else:
+        main()
+        gen_text_and_eval()
