@@ -40,6 +40,14 @@ __device__ __forceinline__ float tanh_f(float v)
     return __builtin_fmaf(2.0f, s, -1.0f);
 }
 
+// streaming (write-once) 16-byte store: non-temporal, does not displace L2 / MALL lines
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_stream4(float *p, float a, float b, float c, float d)
+{
+    f32x4_t v = {a, b, c, d};
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t *>(p));
+}
+
 template <int ACT>
 __device__ __forceinline__ float act_fwd(float v)
 {

@@ -173,8 +173,8 @@ cat_upsample2x_rows(const float *__restrict__ x, const float *__restrict__ feat,
             float *op = oplane + (size_t)(2 * m) * (2 * W);
 #pragma unroll
             for (int e = 0; e < NO; e += 4) {
-                *reinterpret_cast<float4 *>(op + e) = make_float4(o0[e], o0[e + 1], o0[e + 2], o0[e + 3]);
-                *reinterpret_cast<float4 *>(op + 2 * W + e) = make_float4(o1[e], o1[e + 1], o1[e + 2], o1[e + 3]);
+                store_stream4(op + e, o0[e], o0[e + 1], o0[e + 2], o0[e + 3]);
+                store_stream4(op + 2 * W + e, o1[e], o1[e + 1], o1[e + 2], o1[e + 3]);
             }
         }
     }

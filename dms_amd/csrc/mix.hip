@@ -95,7 +95,7 @@ mix_fwd_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
                 }
                 if (s < S) {
                     float *Qp = Q + (((long long)s * L + t) * B + b) * M + m;
-                    if (VEC == 4) *reinterpret_cast<float4 *>(Qp) = make_float4(q[0], q[1], q[2], q[3]);
+                    if (VEC == 4) *reinterpret_cast<float4 *>(Qp) = make_float4(q[0], q[1], q[2], q[VEC - 1]);
                     else Qp[0] = q[0];
                 }
             }

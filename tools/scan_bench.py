@@ -65,6 +65,12 @@ if __name__ == "__main__":
                 run(5120, B, 1005, 4, 0, nch, depth)
         for nch, depth in [(1, 32), (8, 8), (32, 8), (64, 8)]:
             run(2000, 1, 1005, 3, 1900, nch, depth)
+    if which == "policy":
+        run(5120, 32, 1005, 4, 0, 1, 32)
+        run(5120, 32, 1005, 3, 0, 1, 32)
+        run(5120, 32, 1005, 3, 5120 - 256, 1, 32)
+        run(4096, 128, 1000, 3, 0, 1, 8)
+        run(4096, 128, 1000, 3, 0, 1, 16)
     if which in ("all", "b1"):
         for nch, depth in [(1, 24), (8, 8), (16, 8), (32, 8), (64, 8), (128, 8)]:
             run(5120, 1, 1005, 4, 0, nch, depth)
