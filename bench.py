@@ -96,6 +96,13 @@ class LaunchTimer(object):
         if name == "dmn_cat_upsample2x":
             B, Cx, Cf, H, W = args[3:8]
             return "cat_upsample2x %dx%d" % (H, W), 4 * B * (Cx + Cf) * H * W * 5
+        if name == "dmn_bn_relu":
+            N, C, HW = args[5:8]
+            return "dpn bn_relu (all shapes)", 8 * N * C * HW
+        if name == "dmn_dpn_merge":
+            N, Cb, Cy, c1c, HW = args[7:12]
+            Co = Cb + Cy - c1c
+            return "dpn merge+bn_relu (all shapes)", 4 * N * HW * (Cb + Cy + Co * (2 if args[3] else 1))
         return name, 0
 
     def summary(self):

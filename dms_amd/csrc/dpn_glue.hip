@@ -1,0 +1,141 @@
+// dms_amd/csrc/dpn_glue.hip -- inference-time element-wise glue of the DPN backbone (gfx950).
+//
+// The convolutions of the backbone stay on MIOpen (north_star); what is fused here is the
+// memory-bound glue BETWEEN them, which at B=32 / 512 px costs ~17 ms of a 113 ms step when
+// run as separate torch kernels (profiles/r1_bench_steady_state_per_step.txt: BatchNorm 4.9,
+// ReLU 4.3, cat 4.8, add 3.4 ms):
+//   dmn_bn_relu   : eval-mode BatchNorm2d + ReLU in one pass
+//                   (dmn_pytorch/models/dpn/dpn_model.py:156-177, CatBnAct / BnActConv2d)
+//   dmn_dpn_merge : the dual-path merge  resid = x_s1 + out1 ; dense = cat([x_s2, out2])
+//                   (dpn_model.py:265-269) AND the next block's cat(resid, dense)
+//                   (dpn_model.py:246) in one pass: the block output is ONE contiguous tensor
+//                   [resid | dense] whose channel slices are the two paths.
+#include "common.h"
+
+namespace dmn {
+
+// y = max((x - mean[c]) * scale[c] + bias[c], 0),  scale = weight / sqrt(var + eps)
+template <int VEC>
+__global__ void __launch_bounds__(256)
+bn_relu_kernel(const float *__restrict__ x, const float *__restrict__ mean,
+               const float *__restrict__ scale, const float *__restrict__ bias,
+               float *__restrict__ y, long long total, int C, int HWv)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)((i / HWv) % C);
+        const float m = mean[c], s = scale[c], b = bias[c];
+        if (VEC == 4) {
+            const float4 v = reinterpret_cast<const float4 *>(x)[i];
+            float4 o;
+            o.x = fmaxf(__builtin_fmaf(v.x - m, s, b), 0.0f);
+            o.y = fmaxf(__builtin_fmaf(v.y - m, s, b), 0.0f);
+            o.z = fmaxf(__builtin_fmaf(v.z - m, s, b), 0.0f);
+            o.w = fmaxf(__builtin_fmaf(v.w - m, s, b), 0.0f);
+            reinterpret_cast<float4 *>(y)[i] = o;
+        } else {
+            y[i] = fmaxf(__builtin_fmaf(x[i] - m, s, b), 0.0f);
+        }
+    }
+}
+
+// out (N, Cb + Cy - c1c, HW):  [ base[:, :c1c] + yv[:, :c1c] | base[:, c1c:] | yv[:, c1c:] ]
+// BN: additionally act = relu(bn(out)) -- the NEXT consumer's pre-activation -- while the
+// merged values are still in registers (saves re-reading `out`).
+template <int VEC, bool BN>
+__global__ void __launch_bounds__(256)
+dpn_merge_kernel(const float *__restrict__ base, const float *__restrict__ yv,
+                 float *__restrict__ out, float *__restrict__ act,
+                 const float *__restrict__ mean, const float *__restrict__ scale,
+                 const float *__restrict__ bias,
+                 long long total, int Cb, int Cy, int c1c, int HWv)
+{
+    const int Co = Cb + Cy - c1c;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int hw = (int)(i % HWv);
+        const long long pl = i / HWv;
+        const int c = (int)(pl % Co);
+        const long long n = pl / Co;
+        const long long ib = (n * Cb + c) * HWv + hw;                  // valid when c < Cb
+        const long long iy = (n * Cy + (c < c1c ? c : c - Cb + c1c)) * HWv + hw;
+        float m = 0.0f, s = 0.0f, b = 0.0f;
+        if (BN) { m = mean[c]; s = scale[c]; b = bias[c]; }
+        if (VEC == 4) {
+            float4 o;
+            if (c < c1c) {
+                const float4 a = reinterpret_cast<const float4 *>(base)[ib];
+                const float4 y = reinterpret_cast<const float4 *>(yv)[iy];
+                o = make_float4(a.x + y.x, a.y + y.y, a.z + y.z, a.w + y.w);
+            } else if (c < Cb) {
+                o = reinterpret_cast<const float4 *>(base)[ib];
+            } else {
+                o = reinterpret_cast<const float4 *>(yv)[iy];
+            }
+            reinterpret_cast<float4 *>(out)[i] = o;
+            if (BN) {
+                float4 r;
+                r.x = fmaxf(__builtin_fmaf(o.x - m, s, b), 0.0f);
+                r.y = fmaxf(__builtin_fmaf(o.y - m, s, b), 0.0f);
+                r.z = fmaxf(__builtin_fmaf(o.z - m, s, b), 0.0f);
+                r.w = fmaxf(__builtin_fmaf(o.w - m, s, b), 0.0f);
+                reinterpret_cast<float4 *>(act)[i] = r;
+            }
+        } else {
+            const float o = c < c1c ? base[ib] + yv[iy] : (c < Cb ? base[ib] : yv[iy]);
+            out[i] = o;
+            if (BN) act[i] = fmaxf(__builtin_fmaf(o - m, s, b), 0.0f);
+        }
+    }
+}
+
+static int grid_for(long long items)
+{
+    long long blocks = (items + 255) / 256;
+    const long long cap = (long long)NUM_CU * 16;
+    return (int)(blocks > cap ? cap : (blocks < 1 ? 1 : blocks));
+}
+
+}  // namespace dmn
+
+using namespace dmn;
+
+extern "C" int dmn_bn_relu(const float *x, const float *mean, const float *scale, const float *bias,
+                           float *y, int N, int C, int HW, void *stream)
+{
+    if (!x || !mean || !scale || !bias || !y) return fail(-1, "dmn_bn_relu: NULL pointer");
+    if (N <= 0 || C <= 0 || HW <= 0) return fail(-4, "dmn_bn_relu: bad sizes N=%d C=%d HW=%d", N, C, HW);
+    hipStream_t s = (hipStream_t)stream;
+    if (HW % 4 == 0 && !(((uintptr_t)x | (uintptr_t)y) & 15)) {
+        const long long total = (long long)N * C * (HW / 4);
+        hipLaunchKernelGGL(bn_relu_kernel<4>, dim3(grid_for(total)), dim3(256), 0, s, x, mean, scale, bias, y, total, C, HW / 4);
+    } else {
+        const long long total = (long long)N * C * HW;
+        hipLaunchKernelGGL(bn_relu_kernel<1>, dim3(grid_for(total)), dim3(256), 0, s, x, mean, scale, bias, y, total, C, HW);
+    }
+    return launch_status("dmn_bn_relu");
+}
+
+extern "C" int dmn_dpn_merge(const float *base, const float *yv, float *out, float *act,
+                             const float *mean, const float *scale, const float *bias,
+                             int N, int Cb, int Cy, int c1c, int HW, void *stream)
+{
+    if (!base || !yv || !out) return fail(-1, "dmn_dpn_merge: NULL pointer");
+    if (act && (!mean || !scale || !bias))
+        return fail(-1, "dmn_dpn_merge: act requested without mean/scale/bias");
+    if (N <= 0 || HW <= 0 || c1c <= 0 || Cb < c1c || Cy < c1c)
+        return fail(-4, "dmn_dpn_merge: bad sizes N=%d Cb=%d Cy=%d c1c=%d HW=%d", N, Cb, Cy, c1c, HW);
+    hipStream_t s = (hipStream_t)stream;
+    const int Co = Cb + Cy - c1c;
+    const bool vec = HW % 4 == 0 &&
+                     !(((uintptr_t)base | (uintptr_t)yv | (uintptr_t)out | (uintptr_t)act) & 15);
+    const int hwv = vec ? HW / 4 : HW;
+    const long long total = (long long)N * Co * hwv;
+    const dim3 grid(grid_for(total)), block(256);
+#define DMN_MERGE(V, B) hipLaunchKernelGGL((dpn_merge_kernel<V, B>), grid, block, 0, s, base, yv, out, \
+                                           act, mean, scale, bias, total, Cb, Cy, c1c, hwv)
+    if (vec) { if (act) DMN_MERGE(4, true); else DMN_MERGE(4, false); }
+    else     { if (act) DMN_MERGE(1, true); else DMN_MERGE(1, false); }
+#undef DMN_MERGE
+    return launch_status("dmn_dpn_merge");
+}

@@ -12,11 +12,19 @@ state_dict (names + shapes, so published DMN checkpoints load) and the five pyra
   (dpn_model.py:358-362); output = conv5_bn_ac of the last block (2688 ch for dpn92).
 
 No torchvision import and no URL download: ``pretrained=True`` raises.
+
+Inference fast path (eval mode, grad disabled, fp32 on a ROCm device): the element-wise glue
+between the MIOpen convolutions -- BatchNorm + ReLU, the dual-path add / cat and the next
+block's cat -- runs in two HIP kernels (csrc/dpn_glue.hip) instead of ~6 torch kernels per
+block; a block's output is ONE contiguous [residual | dense] tensor.  Same values (eval-mode
+BN is an affine map; differences are fp32 rounding, ~1e-7 relative).
 """
 from collections import OrderedDict
 
 import torch
 import torch.nn as nn
+
+from .. import ops
 
 BN_EPS = 1e-3
 
@@ -33,6 +41,24 @@ VARIANTS = {
 
 def _join(x):
     return torch.cat(x, dim=1) if isinstance(x, tuple) else x
+
+
+def _bn_consts(bn):
+    """(mean, scale, bias) of an eval-mode BatchNorm2d, cached until its tensors change."""
+    tensors = (bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    key = tuple((t._version, t.data_ptr()) for t in tensors)
+    cached = bn.__dict__.get("_dmn_consts")
+    if cached is None or cached[0] != key:
+        with torch.no_grad():
+            scale = (bn.weight * torch.rsqrt(bn.running_var + bn.eps)).contiguous()
+            cached = (key, (bn.running_mean.detach().contiguous(), scale,
+                            bn.bias.detach().contiguous()))
+        bn.__dict__["_dmn_consts"] = cached
+    return cached[1]
+
+
+def _bn_relu(bn, x):
+    return ops.bn_relu(x, *_bn_consts(bn))
 
 
 class CatBnAct(nn.Module):
@@ -107,6 +133,21 @@ class DualPathBlock(nn.Module):
             o1, o2 = y[:, :self.c1c], y[:, self.c1c:]
         return res + o1, torch.cat([dense, o2], dim=1)
 
+    def forward_fused(self, X, act_a, next_bn):
+        """X: contiguous [residual | dense]; act_a: relu(c1x1_a.bn(X)) if the previous merge
+        already produced it.  Returns (X', relu(next_bn(X')))."""
+        if act_a is None:
+            act_a = _bn_relu(self.c1x1_a.bn, X)
+        if self.kind == "normal":
+            base = X
+        else:
+            w = self.c1x1_w_s2 if self.kind == "down" else self.c1x1_w_s1
+            base = w.conv(_bn_relu(w.bn, X))
+        y = self.c1x1_a.conv(act_a)
+        y = self.c3x3_b.conv(_bn_relu(self.c3x3_b.bn, y))
+        y = self.c1x1_c.conv(_bn_relu(self.c1x1_c.bn, y))
+        return ops.dpn_merge(base, y, self.c1c, _bn_consts(next_bn))
+
 
 class DPN(nn.Module):
     def __init__(self, variant="dpn92"):
@@ -132,8 +173,28 @@ class DPN(nn.Module):
         blocks["conv5_bn_ac"] = CatBnAct(cin)
         self.out_channels = cin
         self.features = nn.Sequential(blocks)
+        self.fusable = not b
+        self.fuse_glue = True          # set False to force the plain torch path
+
+    def _forward_fused(self, x):
+        children = list(self.features.named_children())
+        stem = children[0][1]
+        blocks, final = children[1:-1], children[-1][1]
+        raw = stem.conv(x)
+        X = stem.pool(_bn_relu(stem.bn, raw))
+        feats = [raw]
+        act = None
+        for i, (name, block) in enumerate(blocks):
+            nxt = blocks[i + 1][1].c1x1_a.bn if i + 1 < len(blocks) else final.bn
+            X, act = block.forward_fused(X, act, nxt)
+            if name in self.taps:
+                feats.append(X)
+        return act, feats
 
     def forward(self, x):
+        if (self.fuse_glue and self.fusable and not self.training
+                and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32):
+            return self._forward_fused(x.contiguous())
         feats = []
         out = x
         for name, module in self.features.named_children():

@@ -252,3 +252,46 @@ class _CatUpsample2x(torch.autograd.Function):
 def cat_upsample2x(x, feat):
     """bilinear x2 (align_corners=False) of cat([x, feat], 1), one pass."""
     return _CatUpsample2x.apply(x.contiguous(), feat.contiguous())
+
+
+# ------------------------------------------------------------------------------------
+# DPN backbone glue (inference only: no autograd)
+# ------------------------------------------------------------------------------------
+def _chk_bn(name, consts, C):
+    for t in consts:
+        _chk(name, t, (C,))
+
+
+def bn_relu(x, mean, scale, bias):
+    """relu((x - mean[c]) * scale[c] + bias[c]) for x (N, C, H, W); eval-mode BN + ReLU."""
+    N, C = x.shape[0], x.shape[1]
+    HW = x.shape[2] * x.shape[3]
+    _chk("bn_relu", x)
+    _chk_bn("bn_relu", (mean, scale, bias), C)
+    with torch.cuda.device(x.device):
+        y = torch.empty_like(x)
+        _lib.call("dmn_bn_relu", _ptr(x), _ptr(mean), _ptr(scale), _ptr(bias), _ptr(y),
+                  N, C, HW, _stream())
+    return y
+
+
+def dpn_merge(base, y, c1c, bn=None):
+    """out = [base[:, :c1c] + y[:, :c1c] | base[:, c1c:] | y[:, c1c:]] in one pass.
+
+    bn = (mean, scale, bias) of the next consumer's BatchNorm: also returns relu(bn(out)),
+    written in the same pass; returns (out, act) (act None when bn is None).
+    """
+    N, Cb, H, W = base.shape
+    Cy = y.shape[1]
+    Co = Cb + Cy - c1c
+    _chk("dpn_merge", base)
+    _chk("dpn_merge", y, (N, Cy, H, W))
+    if bn is not None:
+        _chk_bn("dpn_merge", bn, Co)
+    with torch.cuda.device(base.device):
+        out = torch.empty((N, Co, H, W), device=base.device, dtype=torch.float32)
+        act = torch.empty_like(out) if bn is not None else None
+        mean, scale, bias = bn if bn is not None else (None, None, None)
+        _lib.call("dmn_dpn_merge", _ptr(base), _ptr(y), _ptr(out), _ptr(act), _ptr(mean),
+                  _ptr(scale), _ptr(bias), N, Cb, Cy, int(c1c), H * W, _stream())
+    return out, act

@@ -150,6 +150,24 @@ int dmn_cat_upsample2x_bwd(const float *g, float *gx, float *gfeat,
 int dmn_threshold_iou(const float *prob, const float *mask, const float *thresholds,
                       float *inter, float *uni, int B, int N, int NT, void *stream);
 
+/*
+ * Inference-time glue of the DPN backbone (the convolutions stay on MIOpen).
+ * dmn_bn_relu: eval-mode BatchNorm2d followed by ReLU, the `act(bn(x))` of CatBnAct /
+ * BnActConv2d (dmn_pytorch/models/dpn/dpn_model.py:156-177):
+ *   y[n,c,:] = max((x[n,c,:] - mean[c]) * scale[c] + bias[c], 0), scale = weight / sqrt(var + eps)
+ * dmn_dpn_merge: DualPathBlock's merge `resid = x_s1 + out1; dense = cat([x_s2, out2])`
+ * (dpn_model.py:265-269) together with the next block's `cat(resid, dense)` (dpn_model.py:246):
+ *   base (N, Cb, HW) = [x_s1 | x_s2], yv (N, Cy, HW) = [out1 | out2], c1c = width of the residual path
+ *   out (N, Cb + Cy - c1c, HW) = [ base[:, :c1c] + yv[:, :c1c] | base[:, c1c:] | yv[:, c1c:] ]
+ *   act (same shape) or NULL: relu(bn(out)) with the (mean, scale, bias) of the NEXT consumer's
+ *   BatchNorm (the following block's c1x1_a.bn, or conv5_bn_ac), written in the same pass.
+ */
+int dmn_bn_relu(const float *x, const float *mean, const float *scale, const float *bias,
+                float *y, int N, int C, int HW, void *stream);
+int dmn_dpn_merge(const float *base, const float *yv, float *out, float *act,
+                  const float *mean, const float *scale, const float *bias,
+                  int N, int Cb, int Cy, int c1c, int HW, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -338,6 +338,73 @@ def test_whole_dmn_matches_reference_end_to_end():
 
 
 # ------------------------------------------------------------------------------------
+# DPN backbone glue (inference): BN+ReLU and the dual-path merge
+# ------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,C,H,W", [(2, 5, 4, 4), (1, 3, 3, 5), (3, 64, 8, 8), (1, 1, 1, 1)])
+def test_bn_relu_matches_torch_eval_batchnorm(N, C, H, W):
+    bn = torch.nn.BatchNorm2d(C, eps=1e-3)
+    bn.load_state_dict(det_fill_state(bn.state_dict()))
+    bn.running_var.abs_().add_(0.1)
+    bn = bn.to(DEV).eval()
+    x = det_uniform((N, C, H, W), 71, 2.0).to(DEV)
+    scale = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
+    got = ops.bn_relu(x, bn.running_mean, scale.contiguous(), bn.bias.detach())
+    with torch.no_grad():
+        want = torch.relu(bn(x))
+    assert rel_err(got, want) < 1e-6
+
+
+@pytest.mark.parametrize("N,Cb,Cy,c1c,H,W", [(2, 7, 5, 3, 4, 4), (1, 6, 4, 4, 3, 5), (2, 336, 272, 256, 8, 8),
+                                             (1, 4, 4, 4, 2, 2)])
+@pytest.mark.parametrize("with_bn", [False, True])
+def test_dpn_merge_matches_add_and_cat(N, Cb, Cy, c1c, H, W, with_bn):
+    base = det_uniform((N, Cb, H, W), 72, 1.0).to(DEV)
+    y = det_uniform((N, Cy, H, W), 73, 1.0).to(DEV)
+    want = torch.cat([base[:, :c1c] + y[:, :c1c], base[:, c1c:], y[:, c1c:]], 1)
+    Co = Cb + Cy - c1c
+    bn = None
+    if with_bn:
+        bn = (det_uniform((Co,), 74, 1.0).to(DEV), det_uniform((Co,), 75, 1.0).to(DEV).abs() + 0.5,
+              det_uniform((Co,), 76, 1.0).to(DEV))
+    out, act = ops.dpn_merge(base, y, c1c, bn)
+    assert torch.equal(out, want)                               # add + copy: bit exact
+    if with_bn:
+        m, s, b = (t.view(1, -1, 1, 1) for t in bn)
+        assert rel_err(act, torch.relu((want - m) * s + b)) < 1e-6
+    else:
+        assert act is None
+
+
+def test_dpn92_fused_glue_equals_plain_torch_backbone():
+    """Same module, same weights: fast path (HIP glue) vs the plain torch path, all taps."""
+    from dms_amd.models.dpn import DPN
+    net = DPN("dpn92")
+    net.load_state_dict(det_fill_state(net.state_dict()))
+    net = net.to(DEV).eval()
+    img = det_uniform((2, 3, 96, 64), 77, 1.0).to(DEV)
+    with torch.no_grad():
+        out_f, feats_f = net(img)
+        net.fuse_glue = False
+        out_t, feats_t = net(img)
+    assert len(feats_f) == len(feats_t) == 5
+    assert rel_err(out_f, out_t) < 1e-5
+    for a, b in zip(feats_f, feats_t):
+        assert a.shape == b.shape and rel_err(a, b) < 1e-5
+    # weights changed in place (load_state_dict) must invalidate the cached BN constants
+    net.fuse_glue = True
+    with torch.no_grad():
+        net.features.conv5_bn_ac.bn.running_mean.add_(0.25)
+        out_f2, _ = net(img)
+        net.fuse_glue = False
+        out_t2, _ = net(img)
+    assert rel_err(out_f2, out_t2) < 1e-5 and not torch.equal(out_f2, out_f)
+    # training mode / grad enabled keeps the autograd-capable torch path
+    net.fuse_glue = True
+    out_g, _ = net(img)
+    assert out_g.requires_grad
+
+
+# ------------------------------------------------------------------------------------
 # full-size properties (BASELINE.json configs 2 and 5 shapes; no CPU oracle at this size)
 # ------------------------------------------------------------------------------------
 def test_sru_full_size_chunked_equals_whole_and_column_subset_oracle():
