@@ -96,6 +96,9 @@ class LaunchTimer(object):
         if name == "dmn_cat_upsample2x":
             B, Cx, Cf, H, W = args[3:8]
             return "cat_upsample2x %dx%d" % (H, W), 4 * B * (Cx + Cf) * H * W * 5
+        if name == "dmn_sru_state_fwd":
+            T, B, d = args[4:7]
+            return "sru_state (u0|f only) T=%d cols=%d" % (T, B * d), 8 * T * B * d
         if name == "dmn_bn_relu":
             N, C, HW = args[5:8]
             return "dpn bn_relu (all shapes)", 8 * N * C * HW

@@ -31,6 +31,8 @@ void launch_sru_fwd_k4(int act, bool store_c, int depth, dim3 grid, hipStream_t 
                        const float *x, const float *bias, const float *c0, float *h, float *c_all,
                        float *c_last, int T, int ncols, int d, float scale_x, int h_t0,
                        int chunk_len, const float2 *carries);
+void launch_sru_fwd_k2(int depth, dim3 grid, hipStream_t s, const float *U, const float *bias,
+                       const float *c0, float *c_last, int T, int ncols, int d);
 constexpr int WHOLE_SEQUENCE = 0x7fffffff / 2;   // chunk_len of the un-chunked scan
 
 
@@ -228,6 +230,21 @@ extern "C" int dmn_sru_fwd(const float *U, const float *x, const float *bias, co
     if (k == 3) launch_sru_fwd_k3(act, c_all != nullptr, depth, grid, s, U, x, bias, c0, h, c_all, c_last, T, ncols, d, scale_x, h_t0, WHOLE_SEQUENCE, nullptr);
     else        launch_sru_fwd_k4(act, c_all != nullptr, depth, grid, s, U, x, bias, c0, h, c_all, c_last, T, ncols, d, scale_x, h_t0, WHOLE_SEQUENCE, nullptr);
     return launch_status("dmn_sru_fwd");
+}
+
+extern "C" int dmn_sru_state_fwd(const float *U2, const float *bias, const float *c0,
+                                 float *c_last, int T, int B, int d, void *stream)
+{
+    if ((!U2 && T > 0) || !bias || !c_last) return fail(-1, "dmn_sru_state_fwd: U2, bias and c_last must not be NULL");
+    if (T < 0 || B <= 0 || d <= 0) return fail(-4, "dmn_sru_state_fwd: bad sizes T=%d B=%d d=%d", T, B, d);
+    if ((long long)B * d * 2 * 4 * 33 >= 0x7fffffffLL) return fail(-5, "dmn_sru_state_fwd: B*d=%lld too large", (long long)B * d);
+    if ((uintptr_t)U2 & 7) return fail(-7, "dmn_sru_state_fwd: U2 must be 8-byte aligned");
+    const int ncols = B * d;
+    const int nwaves = (ncols + WAVE - 1) / WAVE;
+    int depth = depth_override();
+    if (depth <= 0) depth = (nwaves <= 3 * NUM_CU) ? 32 : (nwaves <= 6 * NUM_CU ? 16 : 8);
+    launch_sru_fwd_k2(depth, dim3(nwaves), (hipStream_t)stream, U2, bias, c0, c_last, T, ncols, d);
+    return launch_status("dmn_sru_state_fwd");
 }
 
 namespace dmn {

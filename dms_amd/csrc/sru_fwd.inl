@@ -63,6 +63,11 @@ __device__ __forceinline__ i32x4 make_srd(const void *base)
 template <int K> struct Slot;
 template <> struct Slot<4> { f32x4 u; };
 template <> struct Slot<3> { f32x3 u; float x; };
+// K = 2: state-only scan over [u0 | forget] pairs -- the steps of the LAST layer whose hidden
+// state nobody reads (dmn.py:209 keeps the last H*W steps) need neither the reset gate nor
+// the highway term, so their projection is computed for 2 of the k columns only.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <> struct Slot<2> { f32x2 u; };
 
 template <int I> struct IC { static constexpr int value = I; };
 template <int I, int N, class F>
@@ -90,6 +95,12 @@ __device__ __forceinline__ void issue_load(Slot<3> &s, i32x4 srdU, i32x4 srdX, u
     asm volatile("buffer_load_dword %0, %1, %2, %3 offen" DMN_LD_POLICY : "+v"(s.x) : "v"(offX), "s"(srdX), "s"(sX) : "memory");
 }
 
+__device__ __forceinline__ void issue_load(Slot<2> &s, i32x4 srdU, i32x4, unsigned offU, unsigned,
+                                           unsigned sU, unsigned)
+{
+    asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" DMN_LD_POLICY : "+v"(s.u) : "v"(offU), "s"(srdU), "s"(sU) : "memory");
+}
+
 // wait until at most N younger VMEM operations are outstanding; naming the slot "+v" makes
 // every consumer of the slot depend on this statement
 template <int N>
@@ -105,6 +116,14 @@ __device__ __forceinline__ void wait_slot(Slot<3> &s)
     asm volatile("s_waitcnt vmcnt(%2)" : "+v"(s.u), "+v"(s.x) : "n"(n) : "memory");
 }
 
+template <int N>
+__device__ __forceinline__ void wait_slot(Slot<2> &s)
+{
+    constexpr int n = N > 63 ? 63 : N;
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(s.u) : "n"(n) : "memory");
+}
+
+__device__ __forceinline__ float4 slot_values(const Slot<2> &s) { return make_float4(s.u.x, s.u.y, 0.0f, 0.0f); }
 __device__ __forceinline__ float4 slot_values(const Slot<4> &s) { return make_float4(s.u.x, s.u.y, s.u.z, s.u.w); }
 __device__ __forceinline__ float4 slot_values(const Slot<3> &s) { return make_float4(s.u.x, s.u.y, s.u.z, s.x); }
 
@@ -263,9 +282,11 @@ sru_fwd_cols(const float *__restrict__ U, const float *__restrict__ x,
         if (t_mid > t_begin)
             cur = scan_range<K, ACT, DEPTH, STORE_C, false>(p, strideU, strideX, offU, offX,
                                                             t_mid - t_begin, cur, bf2, br2, scale_x);
-        if (T > t_mid)
-            cur = scan_range<K, ACT, DEPTH, STORE_C, true>(p, strideU, strideX, offU, offX,
-                                                           T - t_mid, cur, bf2, br2, scale_x);
+        if constexpr (K != 2) {
+            if (T > t_mid)
+                cur = scan_range<K, ACT, DEPTH, STORE_C, true>(p, strideU, strideX, offU, offX,
+                                                               T - t_mid, cur, bf2, br2, scale_x);
+        }
     }
     if (c_last && blockIdx.y == gridDim.y - 1) c_last[col] = cur;
 }
@@ -301,7 +322,15 @@ static void launch_fwd_act(int act, int depth, dim3 grid, hipStream_t s, const f
         launch_fwd<K, DMN_ACT_IDENTITY, STORE_C>(depth, grid, s, U, x, bias, c0, h, c_all, c_last, T, ncols, d, scale_x, h_t0, chunk_len, carries);
 }
 
-
+#if DMN_SRU_K == 2
+// state-only: no h, no c_all, the activation is never applied; the caller passes h_t0 = T
+void DMN_SRU_LAUNCH_NAME(int depth, dim3 grid, hipStream_t s, const float *U, const float *bias,
+                         const float *c0, float *c_last, int T, int ncols, int d)
+{
+    launch_fwd<2, DMN_ACT_IDENTITY, false>(depth, grid, s, U, nullptr, bias, c0, nullptr, nullptr,
+                                           c_last, T, ncols, d, 1.0f, T, 0x7fffffff / 2, nullptr);
+}
+#else
 void DMN_SRU_LAUNCH_NAME(int act, bool store_c, int depth, dim3 grid, hipStream_t s, const float *U,
                          const float *x, const float *bias, const float *c0, float *h,
                          float *c_all, float *c_last, int T, int ncols, int d, float scale_x,
@@ -310,5 +339,6 @@ void DMN_SRU_LAUNCH_NAME(int act, bool store_c, int depth, dim3 grid, hipStream_
     if (store_c) launch_fwd_act<DMN_SRU_K, true>(act, depth, grid, s, U, x, bias, c0, h, c_all, c_last, T, ncols, d, scale_x, h_t0, chunk_len, carries);
     else         launch_fwd_act<DMN_SRU_K, false>(act, depth, grid, s, U, x, bias, c0, h, c_all, c_last, T, ncols, d, scale_x, h_t0, chunk_len, carries);
 }
+#endif
 
 }  // namespace dmn

@@ -91,6 +91,10 @@ class BaseDMN(nn.Module):
     def hot_path(self, vis, lang):
         """vis (B, vis_size, H, W) backbone output, lang (B, L) int64 ->
         (B, hid_mixed, H, W) if high_res else (B, 1, H, W)."""
+        with ops.gemm_backend():
+            return self._hot_path(vis, lang)
+
+    def _hot_path(self, vis, lang):
         B, C, H, W = vis.shape
         S = H * W
         C8 = C + 8

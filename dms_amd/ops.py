@@ -5,6 +5,9 @@ PyTorch is plumbing here: it owns device memory, streams and autograd bookkeepin
 operator below runs in libdmn_hip.so.  Tensors must be fp32 and on a ROCm device --
 anything else raises (there is no CPU or eager fallback).
 """
+import contextlib
+import os
+
 import torch
 
 from . import _lib
@@ -32,6 +35,31 @@ def _chk(name, t, shape=None):
 
 def _ptr(t):
     return None if t is None else t.data_ptr()
+
+
+_BLAS_NAMES = {"rocblas": "cublas", "hipblaslt": "cublaslt"}
+
+
+@contextlib.contextmanager
+def gemm_backend():
+    """Route the hot path's plain fp32 library GEMMs (x.W projections, filter Linear) to the
+    BLAS library that is faster for their shapes on MI355X: rocBLAS, measured 142.6 vs
+    128.8 TFLOP/s (hipBLASLt, torch's default here) on the mSRU projection
+    163840x1005 . 1005x3015 (profiles/r1_gemm_backend_probe.txt).  DMN_GEMM_BACKEND =
+    rocblas | hipblaslt | default overrides.  The preference is process-global in torch, so
+    it is restored on exit; not safe against other threads issuing GEMMs concurrently."""
+    want = os.environ.get("DMN_GEMM_BACKEND", "rocblas")
+    if want == "default":
+        yield
+        return
+    if want not in _BLAS_NAMES:
+        raise RuntimeError("DMN_GEMM_BACKEND must be rocblas, hipblaslt or default (got %r)" % want)
+    prev = torch.backends.cuda.preferred_blas_library()
+    torch.backends.cuda.preferred_blas_library(_BLAS_NAMES[want])
+    try:
+        yield
+    finally:
+        torch.backends.cuda.preferred_blas_library(prev)
 
 
 # ------------------------------------------------------------------------------------
@@ -74,6 +102,20 @@ def sru_forward_raw(u, x, bias, c0, act, scale_x, h_t0=0, want_c=False, nchunks=
                       _ptr(c_all), _ptr(c_last), T, B, d, k, ACT_IDS[act], float(scale_x),
                       int(h_t0), _stream())
     return h, c_all, c_last
+
+
+def sru_state(u2, bias, c0=None):
+    """Cell state after the last step for u2 (T, B, d, 2) = [u0 | forget]; inference only."""
+    T, B, d, two = u2.shape
+    if two != 2:
+        raise RuntimeError("dms_amd.sru_state: expected (T, B, d, 2), got %s" % (tuple(u2.shape),))
+    _chk("sru_state", u2)
+    _chk("sru_state", bias, (2 * d,))
+    _chk("sru_state", c0, (B, d) if c0 is not None else None)
+    with torch.cuda.device(u2.device):
+        c_last = torch.empty((B, d), device=u2.device, dtype=torch.float32)
+        _lib.call("dmn_sru_state_fwd", _ptr(u2), _ptr(bias), _ptr(c0), _ptr(c_last), T, B, d, _stream())
+    return c_last
 
 
 class _SRUCompute(torch.autograd.Function):

@@ -30,6 +30,7 @@ class SRUCell(nn.Module):
         self.scale_x = float(scale_x)
         self.weight = nn.Parameter(torch.empty(n_in, n_out * self.k))
         self.bias = nn.Parameter(torch.empty(n_out * 2))
+        self.state_only_head = True     # inference shortcut of _forward_tail; False = one full scan
         self.init_weight()
 
     def init_weight(self):
@@ -52,6 +53,31 @@ class SRUCell(nn.Module):
         return ops.sru_compute(u.reshape(T, B, self.n_out, 4), None, self.bias, c0,
                                self.activation, self.scale_x, h_t0)
 
+    def _state_weight(self):
+        """The [u0 | forget] columns of ``weight`` as (n_in, n_out*2), cached per weight version."""
+        w = self.weight
+        key = (w._version, w.data_ptr())
+        cached = self.__dict__.get("_w01")
+        if cached is None or cached[0] != key:
+            with torch.no_grad():
+                w01 = w.detach().view(self.n_in, self.n_out, self.k)[:, :, :2].reshape(self.n_in, -1)
+                cached = (key, w01.contiguous())
+            self.__dict__["_w01"] = cached
+        return cached[1]
+
+    def _forward_tail(self, x, c0, h_t0):
+        """Inference, hidden states wanted from step h_t0 on only: the earlier steps reach the
+        output through the cell state alone, so they are projected onto the u0 / forget
+        columns (2 of k: a third less GEMM work for k = 3) and run through the state-only scan."""
+        T, B, n_in = x.shape
+        head = x[:h_t0].reshape(h_t0 * B, n_in)
+        u2 = head.mm(self._state_weight()).view(h_t0, B, self.n_out, 2)
+        c_mid = ops.sru_state(u2, self.bias, c0)
+        tail = x[h_t0:]
+        u = tail.reshape((T - h_t0) * B, n_in).mm(self.weight).view(T - h_t0, B, self.n_out, self.k)
+        return ops.sru_compute(u, tail if self.k == 3 else None, self.bias, c_mid,
+                               self.activation, self.scale_x, 0)
+
     def forward(self, input, c0=None, h_t0=0):
         if input.dim() != 3:
             raise ValueError("SRUCell expects (len, batch, n_in), got %s" % (tuple(input.shape),))
@@ -59,6 +85,11 @@ class SRUCell(nn.Module):
         if n_in != self.n_in:
             raise ValueError("SRUCell: input width %d != n_in %d" % (n_in, self.n_in))
         x = input.contiguous()
+        needs_grad = torch.is_grad_enabled() and (
+            x.requires_grad or self.weight.requires_grad or self.bias.requires_grad
+            or (c0 is not None and c0.requires_grad))
+        if 0 < h_t0 < T and not needs_grad and self.state_only_head:
+            return self._forward_tail(x, c0, h_t0)
         u = x.view(T * B, n_in).mm(self.weight).view(T, B, self.n_out, self.k)
         return ops.sru_compute(u, x if self.k == 3 else None, self.bias, c0,
                                self.activation, self.scale_x, h_t0)

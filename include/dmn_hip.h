@@ -66,6 +66,19 @@ int dmn_sru_fwd_scan(const float *U, const float *x, const float *bias, const fl
                      int nchunks, void *stream);
 
 /*
+ * State-only scan: the cell state after T steps, nothing else.  Same reference interface as
+ * dmn_sru_fwd (the last mSRU layer under dmn.py:204): dmn.py:209 keeps only the last H*W
+ * hidden states, and the steps before them influence the output through c alone, which needs
+ * neither the reset gate nor the highway term.  The caller therefore projects those steps
+ * onto 2 of the k weight columns only (a third less GEMM work) and passes
+ *   U2   (T, B, d, 2)  [u0 | forget pre-activation] per column, 8-byte aligned
+ *   bias (2*d) as in dmn_sru_fwd (only the forget half is read);  c0 (B, d) or NULL
+ *   c_last (B, d): c after step T-1 -- bit-identical to dmn_sru_fwd's c_last on the same u0, u1.
+ */
+int dmn_sru_state_fwd(const float *U2, const float *bias, const float *c0, float *c_last,
+                      int T, int B, int d, void *stream);
+
+/*
  * SRU backward scan (reverse time). Replaces `SRU_Compute.backward` -> `sru_bwd`
  * of the same package (autograd of dmn.py:156,204).
  *   c_all (T,B,d) saved by the forward; grad_h (T,B,d); grad_last (B,d) or NULL.

@@ -114,6 +114,60 @@ def test_sru_bwd_matches_oracle(T, B, d, k, act):
         np.testing.assert_allclose(xg.grad.cpu().numpy(), gx_r, rtol=2e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("T,B,d", [(1, 1, 5), (7, 3, 5), (33, 2, 70), (300, 2, 1005), (64, 1, 64)])
+@pytest.mark.parametrize("k", [3, 4])
+def test_sru_state_only_scan_is_bit_identical_to_full_scan_and_matches_oracle(T, B, d, k):
+    """dmn_sru_state_fwd on the [u0 | forget] columns == c_last of dmn_sru_fwd on all k."""
+    u = det_uniform((T, B, d, k), 51, 2.0)
+    x = det_uniform((T, B, d), 52, 1.0) if k == 3 else None
+    bias = det_uniform((2 * d,), 53, 0.5)
+    c0 = det_uniform((B, d), 54, 1.0)
+    _, _, c_ref = sru_ref.sru_fwd_c(u.numpy(), None if x is None else x.numpy(), bias.numpy(), c0.numpy(), "tanh", 1.0)
+    ud, bd, cd = u.to(DEV), bias.to(DEV), c0.to(DEV)
+    _, _, c_full = ops.sru_forward_raw(ud, None if x is None else x.to(DEV), bd, cd, "tanh", 1.0, nchunks=1)
+    u2 = ud[..., :2].contiguous()
+    c_state = ops.sru_state(u2, bd, cd)
+    assert torch.equal(c_state, c_full)
+    np.testing.assert_allclose(c_state.cpu().numpy(), c_ref, rtol=1e-5, atol=2e-6)
+    assert torch.equal(ops.sru_state(u2, bd, None),
+                       ops.sru_forward_raw(ud, None if x is None else x.to(DEV), bd, None, "tanh", 1.0, nchunks=1)[2])
+
+
+@pytest.mark.parametrize("depth", ["4", "8", "16", "24", "32"])
+def test_sru_state_only_scan_every_prefetch_depth(depth, monkeypatch):
+    monkeypatch.setenv("DMN_SRU_DEPTH", depth)
+    T, B, d = 131, 2, 100
+    u = det_uniform((T, B, d, 3), 55, 2.0).to(DEV)
+    x = det_uniform((T, B, d), 56, 1.0).to(DEV)
+    bias = det_uniform((2 * d,), 57, 0.5).to(DEV)
+    c_full = ops.sru_forward_raw(u, x, bias, None, "tanh", 1.0, nchunks=1)[2]
+    assert torch.equal(ops.sru_state(u[..., :2].contiguous(), bias), c_full)
+
+
+@pytest.mark.parametrize("n_in,n_out", [(24, 24), (16, 24)])
+def test_sru_tail_shortcut_equals_full_scan(n_in, n_out):
+    """Inference with tail=S: the last layer's head steps run state-only on 2 of k columns;
+    result must equal the plain full-length scan (and so the oracle, tested above)."""
+    rnn = dms_amd.SRU(n_in, n_out, num_layers=2)
+    rnn.load_state_dict(det_fill_state(rnn.state_dict()))
+    rnn = rnn.to(DEV).eval()
+    x = det_uniform((90, 3, n_in), 58, 1.0).to(DEV)
+    with torch.no_grad():
+        h_fast, c_fast = rnn(x, tail=12)
+        for cell in rnn.rnn_lst:
+            cell.state_only_head = False
+        h_full, c_full = rnn(x, tail=12)
+        h_all, _ = rnn(x)
+    assert h_fast.shape == (12, 3, n_out)
+    assert rel_err(h_fast, h_full) < 1e-5 and rel_err(c_fast, c_full) < 1e-5
+    assert rel_err(h_fast, h_all[-12:]) < 1e-5
+    # with autograd the shortcut is not taken and gradients flow
+    for cell in rnn.rnn_lst:
+        cell.state_only_head = True
+    h_g, _ = rnn(x, tail=12)
+    assert h_g.requires_grad and rel_err(h_g.detach(), h_full) < 1e-5
+
+
 def test_sru_module_stack_matches_oracle_and_autograd():
     torch.manual_seed(5)
     rnn = dms_amd.SRU(12, 20, num_layers=3).to(DEV)
