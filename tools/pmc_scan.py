@@ -14,3 +14,9 @@ for (T, B, d, k, h_t0) in [(5120, 32, 1005, 4, 0), (5120, 32, 1005, 3, 0), (5120
         ops.sru_forward_raw(u, x, bias, None, "tanh", 1.0, h_t0, want_c=False, nchunks=1)
     torch.cuda.synchronize()
     del u, x
+# state-only head of the last mSRU layer (u0 | forget columns)
+u2 = torch.randn((4864, 32, 1005, 2), device=dev, generator=g)
+bias = 0.1 * torch.randn((2 * 1005,), device=dev, generator=g)
+for _ in range(3):
+    ops.sru_state(u2, bias)
+torch.cuda.synchronize()
