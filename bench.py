@@ -96,6 +96,12 @@ class LaunchTimer(object):
         if name == "dmn_cat_upsample2x":
             B, Cx, Cf, H, W = args[3:8]
             return "cat_upsample2x %dx%d" % (H, W), 4 * B * (Cx + Cf) * H * W * 5
+        if name == "dmn_wino_cat_upsample2x_transform":
+            B, Cx, Cf, H, W = args[3:8]
+            return "wino_in (cat+up+B^T d B) %dx%d" % (H, W), 4 * B * (Cx + Cf) * H * W * 17
+        if name == "dmn_wino_output_transform":
+            B, Co, H, W = args[3:7]
+            return "wino_out (A^T M A) %dx%d" % (H, W), 4 * B * Co * H * W * 20
         if name == "dmn_sru_state_fwd":
             T, B, d = args[4:7]
             return "sru_state (u0|f only) T=%d cols=%d" % (T, B * d), 8 * T * B * d

@@ -213,6 +213,33 @@ class UpsamplingModule(nn.Module):
             in_channels = int(out_channels)
         self.out_layer = nn.Conv2d(in_channels, 1, kernel_size=1, padding=0)
         self.convs = nn.ModuleList(levels)
+        # inference: run a level's cat + upsample + 3x3 conv as fused Winograd transforms around a
+        # batched rocBLAS GEMM.  "auto" = where measured faster than MIOpen (wide levels),
+        # True = every eligible level, False = never.
+        self.winograd = "auto"
+
+    def _wino_weight(self, conv):
+        """U = G g G^T (16, Cout, C) of a level's conv weight, cached per weight version."""
+        w = conv.weight
+        key = (w._version, w.data_ptr())
+        cached = conv.__dict__.get("_dmn_wino")
+        if cached is None or cached[0] != key:
+            with torch.no_grad():
+                cached = (key, ops.wino_filter_transform(w.detach()))
+            conv.__dict__["_dmn_wino"] = cached
+        return cached[1]
+
+    def _use_winograd(self, conv, x, f):
+        if (self.winograd is False or self.mode != 'bilinear' or torch.is_grad_enabled()
+                or not x.is_cuda or conv.kernel_size != (3, 3) or conv.padding != (1, 1)
+                or conv.stride != (1, 1) or conv.dilation != (1, 1) or conv.groups != 1):
+            return False
+        if self.winograd is True:
+            return True
+        # measured on MI355X (profiles/r1_wino_probe.txt): the 16 GEMMs win while Cout >= 128;
+        # below that they turn memory-bound on V and MIOpen's direct kernels are faster
+        tiles = x.shape[0] * x.shape[2] * x.shape[3]
+        return conv.out_channels >= 128 and conv.in_channels >= 256 and tiles >= 2048
 
     def forward(self, x, features):
         i = len(features) - 1
@@ -220,11 +247,21 @@ class UpsamplingModule(nn.Module):
             f = features[i]
             if x.shape[-2:] != f.shape[-2:]:                      # dmn.py:332-336
                 x = F.interpolate(x, f.shape[-2:], mode='bilinear', align_corners=False)
-            if self.mode == 'bilinear':
-                x = ops.cat_upsample2x(x, f)                      # dmn.py:337 + Upsample
+            conv = level[1]
+            if self._use_winograd(conv, x, f):
+                B, _, H, W = x.shape
+                V = ops.wino_cat_upsample2x_transform(x.contiguous(), f.contiguous())
+                with ops.gemm_backend():
+                    M = torch.bmm(self._wino_weight(conv), V)
+                x = ops.wino_output_transform(M, conv.bias, B, H, W)
+                rest = list(level)[2:]
             else:
-                x = self.up(torch.cat([x, f], dim=1))
-            for layer in list(level)[1:]:
+                if self.mode == 'bilinear':
+                    x = ops.cat_upsample2x(x, f)                  # dmn.py:337 + Upsample
+                else:
+                    x = self.up(torch.cat([x, f], dim=1))
+                rest = list(level)[1:]
+            for layer in rest:
                 x = layer(x)
             i -= 1
         return self.out_layer(x)

@@ -9,6 +9,7 @@ and in practice sit near 1e-6.
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 import dms_amd
 from dms_amd import _lib, ops
@@ -369,6 +370,66 @@ def test_upsampling_module_matches_reference_golden():
     with torch.no_grad():
         y = up(x, feats).cpu()
     assert rel_err(y, g["out_mis"]) < 1e-4
+
+
+@pytest.mark.parametrize("B,Cx,Cf,H,W,Cout", [(2, 3, 5, 4, 8, 6), (1, 2, 3, 3, 5, 4), (1, 4, 0, 2, 4, 3),
+                                              (2, 16, 16, 16, 16, 32), (1, 3, 2, 1, 1, 2), (1, 2, 2, 1, 4, 2),
+                                              (3, 5, 4, 7, 12, 9)])
+def test_winograd_level_matches_cat_upsample_conv(B, Cx, Cf, H, W, Cout):
+    """transform -> 16 GEMMs -> transform == conv3x3(upsample2x(cat)) (dmn.py:324,337-338)."""
+    x = det_uniform((B, Cx, H, W), 81, 1.0).to(DEV)
+    f = det_uniform((B, Cf, H, W), 82, 1.0).to(DEV)
+    w = det_uniform((Cout, Cx + Cf, 3, 3), 83, 0.3).to(DEV)
+    bias = det_uniform((Cout,), 84, 0.5).to(DEV)
+    up = F.interpolate(torch.cat([x, f], 1), scale_factor=2, mode="bilinear", align_corners=False)
+    want = F.conv2d(up.double(), w.double(), bias.double(), padding=1).float()
+    V = ops.wino_cat_upsample2x_transform(x, f)
+    assert V.shape == (16, Cx + Cf, B * H * W)
+    M = torch.bmm(ops.wino_filter_transform(w), V)
+    got = ops.wino_output_transform(M, bias, B, H, W)
+    assert got.shape == want.shape and rel_err(got, want) < 1e-5
+    got_nobias = ops.wino_output_transform(M, None, B, H, W)
+    assert rel_err(got_nobias + bias.view(1, -1, 1, 1), want) < 1e-5
+
+
+def test_upsampling_module_winograd_path_matches_reference_golden():
+    g = load_golden("upsample_small")
+    fch = [6, 5, 4, 3, 2]
+    up = dms_amd.UpsamplingModule(7, mode="bilinear", ker_size=3, amplification=8, feature_channels=fch)
+    up.load_state_dict(det_fill_state(up.state_dict()))
+    up = up.to(DEV).eval()
+    up.winograd = True
+    x = det_uniform((1, 7, 3, 4), 303, 1.0).to(DEV)
+    feats = [None, None, det_uniform((1, fch[2], 12, 16), 306, 1.0).to(DEV),
+             det_uniform((1, fch[1], 6, 8), 305, 1.0).to(DEV), det_uniform((1, fch[0], 3, 4), 304, 1.0).to(DEV)]
+    with torch.no_grad():
+        y = up(x, feats).cpu()
+        up.winograd = False
+        y_plain = up(x, feats).cpu()
+    assert rel_err(y, g["out"]) < 1e-4 and rel_err(y, y_plain) < 1e-5
+    up.winograd = True
+    feats = [None, None, det_uniform((1, fch[2], 13, 15), 309, 1.0).to(DEV),
+             det_uniform((1, fch[1], 7, 9), 308, 1.0).to(DEV), det_uniform((1, fch[0], 4, 5), 307, 1.0).to(DEV)]
+    with torch.no_grad():
+        y = up(x, feats).cpu()                                 # resize branch + odd widths (scalar kernels)
+    assert rel_err(y, g["out_mis"]) < 1e-4
+    # with autograd the plain path runs
+    y_g = up(x, feats)
+    assert y_g.requires_grad
+
+
+def test_whole_dmn_winograd_head_matches_reference_end_to_end():
+    g = load_golden("dmn_e2e_64px_highres")
+    net = dms_amd.DMN(100, num_filters=10, lang_layers=3, mix_we=True, pretrained=False,
+                      high_res=True, upsampling_mode="bilinear", upsampling_amplification=32)
+    torch.nn.Module.load_state_dict(net, det_fill_state(net.state_dict()))
+    net = net.to(DEV).eval()
+    net.upsample.winograd = True
+    img = det_uniform((1, 3, 64, 64), 404, 1.0).to(DEV)
+    words = det_ints((1, 6), 405, 100).to(DEV)
+    with torch.no_grad():
+        y = net(img, words).cpu()
+    assert rel_err(y, g["out"]) < 1e-4
 
 
 def test_whole_dmn_matches_reference_end_to_end():
