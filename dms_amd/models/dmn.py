@@ -180,6 +180,9 @@ class BaseDMN(nn.Module):
         return ops.cat_coords(z)
 
 
+WINO_MIN_COUT = 64      # "auto": narrowest level that still goes through the Winograd GEMMs
+
+
 class _Up(nn.Module):
     """Parameter-free placeholder at index 0 of each level so that the convolution keeps
     the reference's key ``convs.{i}.1`` (dmn.py:322-324)."""
@@ -214,32 +217,38 @@ class UpsamplingModule(nn.Module):
         self.out_layer = nn.Conv2d(in_channels, 1, kernel_size=1, padding=0)
         self.convs = nn.ModuleList(levels)
         # inference: run a level's cat + upsample + 3x3 conv as fused Winograd transforms around a
-        # batched rocBLAS GEMM.  "auto" = where measured faster than MIOpen (wide levels),
-        # True = every eligible level, False = never.
+        # batched rocBLAS GEMM.  "auto" = F(4x4) where measured faster than MIOpen, True / "f4" =
+        # every eligible level, "f2" = F(2x2) (error ~7e-7 instead of ~1e-5 per level), False = never.
         self.winograd = "auto"
 
-    def _wino_weight(self, conv):
-        """U = G g G^T (16, Cout, C) of a level's conv weight, cached per weight version."""
+    def _wino_weight(self, conv, m):
+        """U = G g G^T of a level's conv weight, cached per weight version and tile size."""
         w = conv.weight
-        key = (w._version, w.data_ptr())
+        key = (w._version, w.data_ptr(), m)
         cached = conv.__dict__.get("_dmn_wino")
         if cached is None or cached[0] != key:
             with torch.no_grad():
-                cached = (key, ops.wino_filter_transform(w.detach()))
+                cached = (key, ops.wino_filter_transform(w.detach(), m))
             conv.__dict__["_dmn_wino"] = cached
         return cached[1]
 
-    def _use_winograd(self, conv, x, f):
-        if (self.winograd is False or self.mode != 'bilinear' or torch.is_grad_enabled()
+    def _winograd_tile(self, conv, x):
+        """0 = MIOpen path, else the Winograd output tile size m for this level."""
+        mode = self.winograd
+        if (mode is False or self.mode != 'bilinear' or torch.is_grad_enabled()
                 or not x.is_cuda or conv.kernel_size != (3, 3) or conv.padding != (1, 1)
                 or conv.stride != (1, 1) or conv.dilation != (1, 1) or conv.groups != 1):
-            return False
-        if self.winograd is True:
-            return True
-        # measured on MI355X (profiles/r1_wino_probe.txt): the 16 GEMMs win while Cout >= 128;
-        # below that they turn memory-bound on V and MIOpen's direct kernels are faster
-        tiles = x.shape[0] * x.shape[2] * x.shape[3]
-        return conv.out_channels >= 128 and conv.in_channels >= 256 and tiles >= 2048
+            return 0
+        even = x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
+        if mode == "f2":
+            return 2
+        if mode is True or mode == "f4":
+            return 4 if even else 2
+        # "auto", measured on MI355X (profiles/r1_wino_probe.txt): the batched GEMMs win while
+        # the level is wide; narrow levels turn memory-bound on V and MIOpen's kernels are faster
+        if conv.out_channels >= WINO_MIN_COUT and conv.in_channels >= 256:
+            return 4 if even else 2
+        return 0
 
     def forward(self, x, features):
         i = len(features) - 1
@@ -248,12 +257,13 @@ class UpsamplingModule(nn.Module):
             if x.shape[-2:] != f.shape[-2:]:                      # dmn.py:332-336
                 x = F.interpolate(x, f.shape[-2:], mode='bilinear', align_corners=False)
             conv = level[1]
-            if self._use_winograd(conv, x, f):
+            m = self._winograd_tile(conv, x)
+            if m:
                 B, _, H, W = x.shape
-                V = ops.wino_cat_upsample2x_transform(x.contiguous(), f.contiguous())
+                V = ops.wino_cat_upsample2x_transform(x.contiguous(), f.contiguous(), m)
                 with ops.gemm_backend():
-                    M = torch.bmm(self._wino_weight(conv), V)
-                x = ops.wino_output_transform(M, conv.bias, B, H, W)
+                    M = torch.bmm(self._wino_weight(conv, m), V)
+                x = ops.wino_output_transform(M, conv.bias, B, H, W, m)
                 rest = list(level)[2:]
             else:
                 if self.mode == 'bilinear':

@@ -299,38 +299,46 @@ def cat_upsample2x(x, feat):
 # ------------------------------------------------------------------------------------
 # Winograd F(2x2, 3x3) halves of a head level (inference only: no autograd)
 # ------------------------------------------------------------------------------------
-_WINO_G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))
+_WINO_G = {
+    2: ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0)),
+    4: ((1 / 4, 0.0, 0.0), (-1 / 6, -1 / 6, -1 / 6), (-1 / 6, 1 / 6, -1 / 6),
+        (1 / 24, 1 / 12, 1 / 6), (1 / 24, -1 / 12, 1 / 6), (0.0, 0.0, 1.0)),
+}
 
 
-def wino_filter_transform(weight):
-    """U (16, Cout, C) = G g G^T of a (Cout, C, 3, 3) weight (tiny; plain torch)."""
-    G = torch.tensor(_WINO_G, dtype=weight.dtype, device=weight.device)
+def wino_filter_transform(weight, m=2):
+    """U ((m+2)^2, Cout, C) = G g G^T of a (Cout, C, 3, 3) weight (tiny; plain torch, fp64 inside)."""
+    G = torch.tensor(_WINO_G[m], dtype=torch.float64, device=weight.device)
     Cout, C = weight.shape[:2]
-    return torch.einsum("ij,ocjk,lk->iloc", G, weight, G).reshape(16, Cout, C).contiguous()
+    U = torch.einsum("ij,ocjk,lk->iloc", G, weight.double(), G)
+    return U.reshape((m + 2) ** 2, Cout, C).to(weight.dtype).contiguous()
 
 
-def wino_cat_upsample2x_transform(x, feat):
-    """V (16, Cx+Cf, B*H*W): input transform of conv3x3(pad 1) applied to
-    upsample2x_bilinear(cat([x, feat], 1)), straight from the low-res tensors."""
+def wino_cat_upsample2x_transform(x, feat, m=2):
+    """V ((m+2)^2, Cx+Cf, tiles): input transform of conv3x3(pad 1) applied to
+    upsample2x_bilinear(cat([x, feat], 1)), straight from the low-res tensors.
+    tiles = B * (2H/m) * (2W/m); m = 4 needs even H, W."""
     B, Cx, H, W = x.shape
     Cf = feat.shape[1]
     _chk("wino_cat_upsample2x_transform", x)
     _chk("wino_cat_upsample2x_transform", feat, (B, Cf, H, W))
+    tiles = B * (2 * H // m) * (2 * W // m)
     with torch.cuda.device(x.device):
-        V = torch.empty((16, Cx + Cf, B * H * W), device=x.device, dtype=torch.float32)
+        V = torch.empty(((m + 2) ** 2, Cx + Cf, tiles), device=x.device, dtype=torch.float32)
         _lib.call("dmn_wino_cat_upsample2x_transform", _ptr(x), _ptr(feat), _ptr(V), B, Cx, Cf, H, W,
-                  _stream())
+                  int(m), _stream())
     return V
 
 
-def wino_output_transform(M, bias, B, H, W):
-    """out (B, Cout, 2H, 2W) = A^T M A + bias from M (16, Cout, B*H*W)."""
+def wino_output_transform(M, bias, B, H, W, m=2):
+    """out (B, Cout, 2H, 2W) = A^T M A + bias from M ((m+2)^2, Cout, tiles); H, W low-res size."""
     Cout = M.shape[1]
-    _chk("wino_output_transform", M, (16, Cout, B * H * W))
+    _chk("wino_output_transform", M, ((m + 2) ** 2, Cout, B * (2 * H // m) * (2 * W // m)))
     _chk("wino_output_transform", bias, (Cout,) if bias is not None else None)
     with torch.cuda.device(M.device):
         out = torch.empty((B, Cout, 2 * H, 2 * W), device=M.device, dtype=torch.float32)
-        _lib.call("dmn_wino_output_transform", _ptr(M), _ptr(bias), _ptr(out), B, Cout, H, W, _stream())
+        _lib.call("dmn_wino_output_transform", _ptr(M), _ptr(bias), _ptr(out), B, Cout, H, W, int(m),
+                  _stream())
     return out
 
 

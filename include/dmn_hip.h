@@ -152,21 +152,24 @@ int dmn_cat_upsample2x_bwd(const float *g, float *gx, float *gfeat,
                            int B, int Cx, int Cf, int H, int W, void *stream);
 
 /*
- * High-res head level at inference, Winograd F(2x2, 3x3) split so that the multiply part of the
- * 3x3 convolution is a plain batched GEMM (rocBLAS fp32: ~300 TFLOP/s conv-equivalent vs
- * MIOpen's 111-122).  Replaces, for one level of UpsamplingModule.forward (dmn.py:324,337-338),
- *   conv3x3(Upsample(x2, bilinear)(cat([x, feat], 1)))  ->  transform, 16 GEMMs, transform:
+ * High-res head level at inference, Winograd F(m x m, 3x3), m = 2 or 4, split so that the
+ * multiply part of the 3x3 convolution is a plain batched GEMM (rocBLAS fp32: ~300 (m=2) /
+ * ~530 (m=4) TFLOP/s conv-equivalent vs MIOpen's 111-122).  Replaces, for one level of
+ * UpsamplingModule.forward (dmn.py:324,337-338),
+ *   conv3x3(Upsample(x2, bilinear)(cat([x, feat], 1)))  ->  transform, (m+2)^2 GEMMs, transform:
  * dmn_wino_cat_upsample2x_transform: cat + upsample + input transform B^T d B in one pass; the
- *   upsampled tensor is never materialised (tile (ty,tx) depends on the 3x3 low-res neighbourhood).
- *   x (B, Cx, H, W), feat (B, Cf, H, W) -> V (16, Cx+Cf, B*H*W), tile index (b*H + ty)*W + tx
- * caller: M[xi] = U[xi] . V[xi] with U (16, Cout, Cx+Cf) = G g G^T of the conv weight
+ *   upsampled tensor is never materialised (an up-res tile depends on a 3x3 (m=2) / 4x4 (m=4)
+ *   low-res neighbourhood only).  n = m + 2, tiles NT = B * (2H/m) * (2W/m), row-major (b, ty, tx).
+ *   x (B, Cx, H, W), feat (B, Cf, H, W) -> V (n*n, Cx+Cf, NT);  m = 4 needs even H and W.
+ * caller: M[xi] = U[xi] . V[xi] with U (n*n, Cout, Cx+Cf) = G g G^T of the conv weight
  * dmn_wino_output_transform: out (B, Cout, 2H, 2W) = A^T M A + bias[o] (bias may be NULL)
- *   M (16, Cout, B*H*W)
+ *   M (n*n, Cout, NT)
+ * fp32 error of the whole level vs direct convolution: ~7e-7 (m=2), ~1e-5 (m=4) relative.
  */
 int dmn_wino_cat_upsample2x_transform(const float *x, const float *feat, float *V,
-                                      int B, int Cx, int Cf, int H, int W, void *stream);
+                                      int B, int Cx, int Cf, int H, int W, int m, void *stream);
 int dmn_wino_output_transform(const float *M, const float *bias, float *out,
-                              int B, int Cout, int H, int W, void *stream);
+                              int B, int Cout, int H, int W, int m, void *stream);
 
 /*
  * Evaluation threshold sweep.  Replaces, per sample, the loop

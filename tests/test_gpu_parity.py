@@ -374,22 +374,29 @@ def test_upsampling_module_matches_reference_golden():
 
 @pytest.mark.parametrize("B,Cx,Cf,H,W,Cout", [(2, 3, 5, 4, 8, 6), (1, 2, 3, 3, 5, 4), (1, 4, 0, 2, 4, 3),
                                               (2, 16, 16, 16, 16, 32), (1, 3, 2, 1, 1, 2), (1, 2, 2, 1, 4, 2),
-                                              (3, 5, 4, 7, 12, 9)])
-def test_winograd_level_matches_cat_upsample_conv(B, Cx, Cf, H, W, Cout):
-    """transform -> 16 GEMMs -> transform == conv3x3(upsample2x(cat)) (dmn.py:324,337-338)."""
+                                              (3, 5, 4, 7, 12, 9), (1, 3, 3, 2, 2, 2), (2, 4, 3, 6, 10, 5),
+                                              (1, 8, 8, 8, 24, 4)])
+@pytest.mark.parametrize("m", [2, 4])
+def test_winograd_level_matches_cat_upsample_conv(B, Cx, Cf, H, W, Cout, m):
+    """transform -> (m+2)^2 GEMMs -> transform == conv3x3(upsample2x(cat)) (dmn.py:324,337-338)."""
     x = det_uniform((B, Cx, H, W), 81, 1.0).to(DEV)
     f = det_uniform((B, Cf, H, W), 82, 1.0).to(DEV)
+    if m == 4 and (H % 2 or W % 2):
+        with pytest.raises(RuntimeError, match="even"):
+            ops.wino_cat_upsample2x_transform(x, f, 4)
+        return
     w = det_uniform((Cout, Cx + Cf, 3, 3), 83, 0.3).to(DEV)
     bias = det_uniform((Cout,), 84, 0.5).to(DEV)
     up = F.interpolate(torch.cat([x, f], 1), scale_factor=2, mode="bilinear", align_corners=False)
     want = F.conv2d(up.double(), w.double(), bias.double(), padding=1).float()
-    V = ops.wino_cat_upsample2x_transform(x, f)
-    assert V.shape == (16, Cx + Cf, B * H * W)
-    M = torch.bmm(ops.wino_filter_transform(w), V)
-    got = ops.wino_output_transform(M, bias, B, H, W)
-    assert got.shape == want.shape and rel_err(got, want) < 1e-5
-    got_nobias = ops.wino_output_transform(M, None, B, H, W)
-    assert rel_err(got_nobias + bias.view(1, -1, 1, 1), want) < 1e-5
+    V = ops.wino_cat_upsample2x_transform(x, f, m)
+    assert V.shape == ((m + 2) ** 2, Cx + Cf, B * (2 * H // m) * (2 * W // m))
+    M = torch.bmm(ops.wino_filter_transform(w, m), V)
+    got = ops.wino_output_transform(M, bias, B, H, W, m)
+    tol = 1e-5 if m == 2 else 5e-5                     # F(4x4) trades ~15x of fp32 accuracy for speed
+    assert got.shape == want.shape and rel_err(got, want) < tol
+    got_nobias = ops.wino_output_transform(M, None, B, H, W, m)
+    assert rel_err(got_nobias + bias.view(1, -1, 1, 1), want) < tol
 
 
 def test_upsampling_module_winograd_path_matches_reference_golden():
@@ -398,15 +405,18 @@ def test_upsampling_module_winograd_path_matches_reference_golden():
     up = dms_amd.UpsamplingModule(7, mode="bilinear", ker_size=3, amplification=8, feature_channels=fch)
     up.load_state_dict(det_fill_state(up.state_dict()))
     up = up.to(DEV).eval()
-    up.winograd = True
     x = det_uniform((1, 7, 3, 4), 303, 1.0).to(DEV)
     feats = [None, None, det_uniform((1, fch[2], 12, 16), 306, 1.0).to(DEV),
              det_uniform((1, fch[1], 6, 8), 305, 1.0).to(DEV), det_uniform((1, fch[0], 3, 4), 304, 1.0).to(DEV)]
     with torch.no_grad():
-        y = up(x, feats).cpu()
         up.winograd = False
         y_plain = up(x, feats).cpu()
-    assert rel_err(y, g["out"]) < 1e-4 and rel_err(y, y_plain) < 1e-5
+        up.winograd = "f2"
+        y = up(x, feats).cpu()
+        assert rel_err(y, g["out"]) < 1e-4 and rel_err(y, y_plain) < 1e-5
+        up.winograd = True                                    # F(4x4) on the even levels, F(2x2) on 3x4
+        y = up(x, feats).cpu()
+        assert rel_err(y, g["out"]) < 1e-4 and rel_err(y, y_plain) < 1e-4
     up.winograd = True
     feats = [None, None, det_uniform((1, fch[2], 13, 15), 309, 1.0).to(DEV),
              det_uniform((1, fch[1], 7, 9), 308, 1.0).to(DEV), det_uniform((1, fch[0], 4, 5), 307, 1.0).to(DEV)]
