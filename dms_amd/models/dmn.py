@@ -261,8 +261,7 @@ class UpsamplingModule(nn.Module):
             if m:
                 B, _, H, W = x.shape
                 V = ops.wino_cat_upsample2x_transform(x.contiguous(), f.contiguous(), m)
-                with ops.gemm_backend():
-                    M = torch.bmm(self._wino_weight(conv, m), V)
+                M = ops.tuned_matmul(self._wino_weight(conv, m), V)
                 x = ops.wino_output_transform(M, conv.bias, B, H, W, m)
                 rest = list(level)[2:]
             else:

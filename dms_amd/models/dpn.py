@@ -61,6 +61,14 @@ def _bn_relu(bn, x):
     return ops.bn_relu(x, *_bn_consts(bn))
 
 
+def _conv(conv, x):
+    """Inference convolution: 1x1 / stride 1 goes to the per-shape tuned batched GEMM."""
+    if (conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.groups == 1
+            and conv.padding == (0, 0) and conv.bias is None):
+        return ops.conv1x1(x, conv.weight)
+    return conv(x)
+
+
 class CatBnAct(nn.Module):
     def __init__(self, ch):
         super().__init__()
@@ -142,10 +150,10 @@ class DualPathBlock(nn.Module):
             base = X
         else:
             w = self.c1x1_w_s2 if self.kind == "down" else self.c1x1_w_s1
-            base = w.conv(_bn_relu(w.bn, X))
-        y = self.c1x1_a.conv(act_a)
+            base = _conv(w.conv, _bn_relu(w.bn, X))
+        y = _conv(self.c1x1_a.conv, act_a)
         y = self.c3x3_b.conv(_bn_relu(self.c3x3_b.bn, y))
-        y = self.c1x1_c.conv(_bn_relu(self.c1x1_c.bn, y))
+        y = _conv(self.c1x1_c.conv, _bn_relu(self.c1x1_c.bn, y))
         return ops.dpn_merge(base, y, self.c1c, _bn_consts(next_bn))
 
 

@@ -62,6 +62,60 @@ def gemm_backend():
         torch.backends.cuda.preferred_blas_library(prev)
 
 
+_BMM_CHOICE = {}
+
+
+def _time_matmul(name, a, b, reps=3):
+    torch.backends.cuda.preferred_blas_library(name)
+    torch.matmul(a, b)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        torch.matmul(a, b)
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1)
+
+
+def tuned_matmul(a, b):
+    """torch.matmul(a, b) with the BLAS library (rocBLAS / hipBLASLt) chosen PER SHAPE: neither
+    wins everywhere on MI355X (profiles/r1_conv1x1_backend_probe.txt: hipBLASLt is 10-25 % faster
+    on DPN92's conv2_x / conv4_x 1x1 shapes, rocBLAS on the others and on the mSRU projections).
+    The choice is timed once per shape on first use (a few launches and one event wait; not
+    during stream capture, where rocBLAS is used) and cached for the process, so results are
+    reproducible within a process and may differ in the last bits between processes.
+    DMN_GEMM_TUNE=0 disables the timing (always rocBLAS).  Inference only (operands detached:
+    torch.matmul folds -- and copies -- a broadcast operand that requires grad)."""
+    a, b = a.detach(), b.detach()
+    key = (tuple(a.shape), tuple(b.shape), a.device.index)
+    prev = torch.backends.cuda.preferred_blas_library()
+    try:
+        choice = _BMM_CHOICE.get(key)
+        if choice is None:
+            if os.environ.get("DMN_GEMM_TUNE", "1") == "0" or torch.cuda.is_current_stream_capturing():
+                choice = "cublas"
+            else:
+                t = {name: _time_matmul(name, a, b) for name in ("cublas", "cublaslt")}
+                choice = min(t, key=t.get)
+                _BMM_CHOICE[key] = choice
+        torch.backends.cuda.preferred_blas_library(choice)
+        out = torch.matmul(a, b)
+    finally:
+        torch.backends.cuda.preferred_blas_library(prev)
+    return out
+
+
+def conv1x1(x, weight):
+    """1x1 / stride-1 convolution of an NCHW tensor as the batched library GEMM
+    W (Cout x Cin) . X[n] (Cin x HW) -- what MIOpen itself runs for this case (its result is
+    bit-identical to the rocBLAS call) -- through tuned_matmul."""
+    N, Cin, H, W = x.shape
+    Cout = weight.shape[0]
+    _chk("conv1x1", x)
+    out = tuned_matmul(weight.view(Cout, Cin), x.view(N, Cin, H * W))
+    return out.view(N, Cout, H, W)
+
+
 # ------------------------------------------------------------------------------------
 # SRU scan
 # ------------------------------------------------------------------------------------
