@@ -158,6 +158,34 @@ def build_model(device, high_res=True):
     return net.to(device).eval()
 
 
+def serving_latency(net, device, reps=30):
+    """Batch-1 latency of the same model (the reference's own serving shape, dmn.py:142):
+    eager launches vs one captured HIP graph (dms_amd.GraphedDMN).  Extra information, not
+    part of `value`."""
+    import dms_amd
+    g = torch.Generator(device=device).manual_seed(SEED)
+    img = torch.randn((1, 3, 512, 512), device=device, generator=g)
+    words = torch.randint(0, 1000, (1, 20), device=device, generator=g)
+
+    def timeit(fn):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    with torch.no_grad():
+        eager = timeit(lambda: net(img, words))
+        graphed = dms_amd.GraphedDMN(net, 1, 512, 512, 20)
+        replay = timeit(lambda: graphed(img, words))
+        same = bool(torch.equal(graphed(img, words), net(img, words)))
+    return {"workload": "batch-1 512px high-res query", "eager_ms": round(eager, 3),
+            "hip_graph_ms": round(replay, 3), "graph_equals_eager": same}
+
+
 def cpu_baseline_dmn(net, reps, threads):
     """CPU oracle on batch-1 queries of the same workload: torch-CPU DPN92 + reference-
     shaped hot path (oracle.dmn_ref, plain-C SRU scan) + reference-shaped upsampling."""
@@ -421,6 +449,7 @@ def main():
         cb["gpu_vs_oracle_rel_err"] = float((gout - cout).abs().max() / cout.abs().max())
         cb["mask_agreement"] = float(((gout > 0) == (cout > 0)).float().mean())
         line["cpu_baseline"] = cb
+        line["serving_b1"] = serving_latency(net, device)
         # configs[4] microbench beside it (same process, after the timed region)
         row, ms = run_msru_stress(device, 20, 3, timer)
         line["msru_stress"] = {"workload": "T=4096 B=128 d=1000 k=3", "achieved_GBs": row["achieved_GBs"],

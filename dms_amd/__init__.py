@@ -9,9 +9,10 @@ from .models import DMN, BaseDMN, UpsamplingModule
 from .sru import SRU, SRUCell
 from .text import Corpus, Dictionary
 from .metrics import SegmentationEvaluator, threshold_iou
+from .serving import GraphedDMN
 
 VERSION_INFO = (0, 1, 0)
 __version__ = ".".join(map(str, VERSION_INFO))
 
 __all__ = ["DMN", "BaseDMN", "UpsamplingModule", "SRU", "SRUCell", "Corpus", "Dictionary",
-           "SegmentationEvaluator", "threshold_iou"]
+           "SegmentationEvaluator", "threshold_iou", "GraphedDMN"]

@@ -21,19 +21,20 @@ __device__ __forceinline__ long long lbk_off(int t, int b, int k, int B, int K, 
     return ((long long)(t * B + b) * K + k) * ld;
 }
 
-template <int VEC, int KR>    // KR > 0: the K <= KR filter weights of a lane stay in registers
+// KR > 0: the K <= KR filter weights of a lane stay in registers; PT pixels per workgroup
+template <int VEC, int KR, int PT>
 __global__ void __launch_bounds__(256)
 mix_fwd_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
                const float *__restrict__ P, const float *__restrict__ Wp, int ldw,
                float *__restrict__ Q, int B, int L, int K, int S, int M)
 {
-    extern __shared__ float Ps[];            // [L*K][MIX_PT]
+    extern __shared__ float Ps[];            // [L*K][PT]
     // launch order = (piece, b) fastest, pixel tile slowest: workgroups that run together
     // write the same contiguous (s,t) slabs of Q (B*M*4 bytes each) -> DRAM page locality
-    const int b = blockIdx.y, s0 = blockIdx.z * MIX_PT;
+    const int b = blockIdx.y, s0 = blockIdx.z * PT;
     const int LK = L * K;
-    for (int idx = threadIdx.x; idx < LK * MIX_PT; idx += blockDim.x) {
-        const int r = idx / MIX_PT, pp = idx - r * MIX_PT;
+    for (int idx = threadIdx.x; idx < LK * PT; idx += blockDim.x) {
+        const int r = idx / PT, pp = idx - r * PT;
         const int t = r / K, k = r - t * K;
         const int s = s0 + pp;
         Ps[idx] = s < S ? P[lbk_off(t, b, k, B, K, S) + s] : 0.0f;
@@ -55,10 +56,10 @@ mix_fwd_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
                     w[e][k] = k < K ? Wp[(long long)(m + e) * ldw + k] : 0.0f;
         }
         // A rows of the tile's pixels stay in registers; Bt[t] is loaded once per word and
-        // serves all MIX_PT pixels (MIX_PT independent 16-byte stores per load)
-        float a[MIX_PT][VEC];
+        // serves all PT pixels (PT independent 16-byte stores per load)
+        float a[PT][VEC];
 #pragma unroll
-        for (int pp = 0; pp < MIX_PT; ++pp) {
+        for (int pp = 0; pp < PT; ++pp) {
             const int s = s0 + pp < S ? s0 + pp : S - 1;
             const float *Ap = A + ((long long)b * S + s) * M + m;
             if (VEC == 4) { const float4 v = *reinterpret_cast<const float4 *>(Ap); a[pp][0] = v.x; a[pp][1] = v.y; a[pp][2] = v.z; a[pp][3] = v.w; }
@@ -71,7 +72,7 @@ mix_fwd_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
             if (VEC == 4) { const float4 v = *reinterpret_cast<const float4 *>(Bp); bt[0] = v.x; bt[1] = v.y; bt[2] = v.z; bt[3] = v.w; }
             else bt[0] = Bp[0];
 #pragma unroll
-            for (int pp = 0; pp < MIX_PT; ++pp) {
+            for (int pp = 0; pp < PT; ++pp) {
                 const int s = s0 + pp;
                 float q[VEC];
 #pragma unroll
@@ -80,14 +81,14 @@ mix_fwd_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
 #pragma unroll
                     for (int k = 0; k < KR; ++k) {
                         if (k < K) {
-                            const float pv = Ps[(t * K + k) * MIX_PT + pp];
+                            const float pv = Ps[(t * K + k) * PT + pp];
 #pragma unroll
                             for (int e = 0; e < VEC; ++e) q[e] = __builtin_fmaf(w[e][k], pv, q[e]);
                         }
                     }
                 } else {
                     for (int k = 0; k < K; ++k) {
-                        const float pv = Ps[(t * K + k) * MIX_PT + pp];
+                        const float pv = Ps[(t * K + k) * PT + pp];
 #pragma unroll
                         for (int e = 0; e < VEC; ++e)
                             q[e] = __builtin_fmaf(Wp[(long long)(m + e) * ldw + k], pv, q[e]);
@@ -254,14 +255,23 @@ extern "C" int dmn_mix_bcast_add(const float *A, const float *Bt, const float *P
 {
     if (!A || !Bt || !P || !Wp || !Q) return fail(-1, "dmn_mix_bcast_add: NULL pointer");
     if (int rc = check_mix("dmn_mix_bcast_add", B, L, K, S, M, ldw)) return rc;
-    const size_t lds = (size_t)L * K * MIX_PT * sizeof(float);
-    if (lds > 64 * 1024) return fail(-5, "dmn_mix_bcast_add: L*K=%d too large for the LDS stage", L * K);
+    if ((size_t)L * K * MIX_PT * sizeof(float) > 64 * 1024)
+        return fail(-5, "dmn_mix_bcast_add: L*K=%d too large for the LDS stage", L * K);
     hipStream_t s = (hipStream_t)stream;
     const bool vec = (M % 4 == 0) && !(((uintptr_t)A | (uintptr_t)Bt | (uintptr_t)Q) & 15);
     const int pieces = ((vec ? M / 4 : M) + 255) / 256;
-    if ((S + MIX_PT - 1) / MIX_PT > 65535) return fail(-5, "dmn_mix_bcast_add: S=%d too large", S);
-    dim3 grid(pieces, B, (S + MIX_PT - 1) / MIX_PT);
-#define DMN_MIX(V, KR) hipLaunchKernelGGL((mix_fwd_kernel<V, KR>), grid, dim3(256), lds, s, A, Bt, P, Wp, ldw, Q, B, L, K, S, M)
+    if ((S + 1) / 2 > 65535) return fail(-5, "dmn_mix_bcast_add: S=%d too large", S);
+    // few (image, query) pairs (batch-1 serving): 2 pixels per workgroup instead of 8, so that
+    // the launch still has >= 2 workgroups per CU
+    const bool small = (long long)pieces * B * ((S + MIX_PT - 1) / MIX_PT) < 2 * NUM_CU;
+    const int pt = small ? 2 : MIX_PT;
+    const size_t lds = (size_t)L * K * pt * sizeof(float);
+    dim3 grid(pieces, B, (S + pt - 1) / pt);
+#define DMN_MIX(V, KR)                                                                                  \
+    do {                                                                                                \
+        if (small) hipLaunchKernelGGL((mix_fwd_kernel<V, KR, 2>), grid, dim3(256), lds, s, A, Bt, P, Wp, ldw, Q, B, L, K, S, M); \
+        else hipLaunchKernelGGL((mix_fwd_kernel<V, KR, MIX_PT>), grid, dim3(256), lds, s, A, Bt, P, Wp, ldw, Q, B, L, K, S, M); \
+    } while (0)
     if (vec) {
         if (K <= 4) DMN_MIX(4, 4);
         else if (K <= 10) DMN_MIX(4, 10);

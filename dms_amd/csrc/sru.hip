@@ -53,7 +53,7 @@ sru_chunk_aggregate(const float *__restrict__ U, const float *__restrict__ bias,
     float a = 1.0f, b = 0.0f;
     auto load2 = [&](int t) -> float2 {
         const float *p = U + ((size_t)t * nc + col) * K;
-        if (K == 4) return *reinterpret_cast<const float2 *>(p);
+        if (K == 4 || K == 2) return *reinterpret_cast<const float2 *>(p);
         return make_float2(p[0], p[1]);
     };
     if (T > t_begin) {
@@ -245,6 +245,44 @@ extern "C" int dmn_sru_state_fwd(const float *U2, const float *bias, const float
     if (depth <= 0) depth = (nwaves <= 3 * NUM_CU) ? 32 : (nwaves <= 6 * NUM_CU ? 16 : 8);
     launch_sru_fwd_k2(depth, dim3(nwaves), (hipStream_t)stream, U2, bias, c0, c_last, T, ncols, d);
     return launch_status("dmn_sru_state_fwd");
+}
+
+namespace dmn {
+// c_last = composition of the chunk aggregates applied to c0 (state-only time-parallel scan)
+__global__ void __launch_bounds__(256)
+sru_fold_carries(const float2 *__restrict__ carries, const float *__restrict__ c0,
+                 float *__restrict__ c_last, int ncols, int nchunks)
+{
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= ncols) return;
+    float cur = c0 ? c0[col] : 0.0f;
+    for (int cc = 0; cc < nchunks; ++cc) {
+        const float2 ab = carries[(size_t)cc * ncols + col];
+        cur = __builtin_fmaf(ab.x, cur, ab.y);
+    }
+    c_last[col] = cur;
+}
+}  // namespace dmn
+
+extern "C" int dmn_sru_state_fwd_scan(const float *U2, const float *bias, const float *c0,
+                                      float *c_last, float *workspace, int T, int B, int d,
+                                      int nchunks, void *stream)
+{
+    if ((!U2 && T > 0) || !bias || !c_last) return fail(-1, "dmn_sru_state_fwd_scan: U2, bias and c_last must not be NULL");
+    if (T < 0 || B <= 0 || d <= 0) return fail(-4, "dmn_sru_state_fwd_scan: bad sizes T=%d B=%d d=%d", T, B, d);
+    if ((uintptr_t)U2 & 7) return fail(-7, "dmn_sru_state_fwd_scan: U2 must be 8-byte aligned");
+    if (nchunks < 1 || nchunks > 65535) return fail(-9, "dmn_sru_state_fwd_scan: nchunks=%d outside [1, 65535]", nchunks);
+    if (!workspace || ((uintptr_t)workspace & 7)) return fail(-1, "dmn_sru_state_fwd_scan: workspace must be non-NULL, 8-byte aligned");
+    const int ncols = B * d;
+    const int chunk_len = T > 0 ? (T + nchunks - 1) / nchunks : 1;
+    const int used = T > 0 ? (T + chunk_len - 1) / chunk_len : 0;     // chunks that hold steps
+    hipStream_t s = (hipStream_t)stream;
+    float2 *carries = reinterpret_cast<float2 *>(workspace);
+    if (used > 0)
+        hipLaunchKernelGGL((sru_chunk_aggregate<2, 8>), dim3((ncols + WAVE - 1) / WAVE, used), dim3(WAVE), 0, s,
+                           U2, bias, carries, T, ncols, d, chunk_len);
+    hipLaunchKernelGGL(sru_fold_carries, dim3((ncols + 255) / 256), dim3(256), 0, s, carries, c0, c_last, ncols, used);
+    return launch_status("dmn_sru_state_fwd_scan");
 }
 
 namespace dmn {

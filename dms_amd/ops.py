@@ -158,8 +158,9 @@ def sru_forward_raw(u, x, bias, c0, act, scale_x, h_t0=0, want_c=False, nchunks=
     return h, c_all, c_last
 
 
-def sru_state(u2, bias, c0=None):
-    """Cell state after the last step for u2 (T, B, d, 2) = [u0 | forget]; inference only."""
+def sru_state(u2, bias, c0=None, nchunks=None):
+    """Cell state after the last step for u2 (T, B, d, 2) = [u0 | forget]; inference only.
+    Few columns (small B): time is cut into chunks that run concurrently (sru_scan_chunks)."""
     T, B, d, two = u2.shape
     if two != 2:
         raise RuntimeError("dms_amd.sru_state: expected (T, B, d, 2), got %s" % (tuple(u2.shape),))
@@ -168,7 +169,14 @@ def sru_state(u2, bias, c0=None):
     _chk("sru_state", c0, (B, d) if c0 is not None else None)
     with torch.cuda.device(u2.device):
         c_last = torch.empty((B, d), device=u2.device, dtype=torch.float32)
-        _lib.call("dmn_sru_state_fwd", _ptr(u2), _ptr(bias), _ptr(c0), _ptr(c_last), T, B, d, _stream())
+        if nchunks is None:
+            nchunks = sru_scan_chunks(T, B * d)
+        if nchunks > 1:
+            ws = torch.empty(2 * nchunks * B * d, device=u2.device, dtype=torch.float32)
+            _lib.call("dmn_sru_state_fwd_scan", _ptr(u2), _ptr(bias), _ptr(c0), _ptr(c_last), _ptr(ws),
+                      T, B, d, int(nchunks), _stream())
+        else:
+            _lib.call("dmn_sru_state_fwd", _ptr(u2), _ptr(bias), _ptr(c0), _ptr(c_last), T, B, d, _stream())
     return c_last
 
 

@@ -77,6 +77,11 @@ int dmn_sru_fwd_scan(const float *U, const float *x, const float *bias, const fl
  */
 int dmn_sru_state_fwd(const float *U2, const float *bias, const float *c0, float *c_last,
                       int T, int B, int d, void *stream);
+/* time-parallel variant for FEW columns (batch-1 serving), as dmn_sru_fwd_scan is to dmn_sru_fwd:
+ * chunk aggregates (prod f, c | c_in = 0) composed in time order; `workspace` holds
+ * dmn_sru_scan_workspace_floats(T, B, d, nchunks) floats, caller-owned, 8-byte aligned. */
+int dmn_sru_state_fwd_scan(const float *U2, const float *bias, const float *c0, float *c_last,
+                           float *workspace, int T, int B, int d, int nchunks, void *stream);
 
 /*
  * SRU backward scan (reverse time). Replaces `SRU_Compute.backward` -> `sru_bwd`

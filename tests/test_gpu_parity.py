@@ -127,10 +127,13 @@ def test_sru_state_only_scan_is_bit_identical_to_full_scan_and_matches_oracle(T,
     ud, bd, cd = u.to(DEV), bias.to(DEV), c0.to(DEV)
     _, _, c_full = ops.sru_forward_raw(ud, None if x is None else x.to(DEV), bd, cd, "tanh", 1.0, nchunks=1)
     u2 = ud[..., :2].contiguous()
-    c_state = ops.sru_state(u2, bd, cd)
+    c_state = ops.sru_state(u2, bd, cd, nchunks=1)
     assert torch.equal(c_state, c_full)
+    for nch in (2, 5, 64):                                  # time-parallel variant (re-associated)
+        c_par = ops.sru_state(u2, bd, cd, nchunks=nch)
+        np.testing.assert_allclose(c_par.cpu().numpy(), c_ref, rtol=1e-5, atol=2e-6)
     np.testing.assert_allclose(c_state.cpu().numpy(), c_ref, rtol=1e-5, atol=2e-6)
-    assert torch.equal(ops.sru_state(u2, bd, None),
+    assert torch.equal(ops.sru_state(u2, bd, None, nchunks=1),
                        ops.sru_forward_raw(ud, None if x is None else x.to(DEV), bd, None, "tanh", 1.0, nchunks=1)[2])
 
 
@@ -142,7 +145,7 @@ def test_sru_state_only_scan_every_prefetch_depth(depth, monkeypatch):
     x = det_uniform((T, B, d), 56, 1.0).to(DEV)
     bias = det_uniform((2 * d,), 57, 0.5).to(DEV)
     c_full = ops.sru_forward_raw(u, x, bias, None, "tanh", 1.0, nchunks=1)[2]
-    assert torch.equal(ops.sru_state(u[..., :2].contiguous(), bias), c_full)
+    assert torch.equal(ops.sru_state(u[..., :2].contiguous(), bias, nchunks=1), c_full)
 
 
 @pytest.mark.parametrize("n_in,n_out", [(24, 24), (16, 24)])
@@ -529,9 +532,52 @@ def test_dpn92_fused_glue_equals_plain_torch_backbone():
     assert out_g.requires_grad
 
 
+def test_graphed_dmn_replay_equals_eager_forward():
+    """One captured HIP graph per shape: replays must reproduce the eager forward bit for bit,
+    for new inputs as well (static buffers), and reject other shapes."""
+    net = dms_amd.DMN(100, num_filters=10, lang_layers=3, mix_we=True, pretrained=False,
+                      high_res=True, upsampling_mode="bilinear", upsampling_amplification=32)
+    torch.nn.Module.load_state_dict(net, det_fill_state(net.state_dict()))
+    net = net.to(DEV).eval()
+    g = dms_amd.GraphedDMN(net, 2, 64, 96, 6)
+    for seed in (11, 12):
+        img = det_uniform((2, 3, 64, 96), seed, 1.0).to(DEV)
+        words = det_ints((2, 6), seed + 100, 100).to(DEV)
+        with torch.no_grad():
+            want = net(img, words)
+        got = g(img, words).clone()
+        assert got.shape == (2, 1, 64, 96) and torch.equal(got, want)
+    with pytest.raises(RuntimeError, match="captured for"):
+        g(torch.zeros((1, 3, 64, 96), device=DEV), torch.zeros((1, 6), dtype=torch.long, device=DEV))
+
+
 # ------------------------------------------------------------------------------------
 # full-size properties (BASELINE.json configs 2 and 5 shapes; no CPU oracle at this size)
 # ------------------------------------------------------------------------------------
+def test_head_full_size_winograd_equals_miopen_path_and_shards_by_batch():
+    """BASELINE configs[1] head shapes (1005 + [2688, 1552, 704, 336, 64] channels, 16x16 -> 512x512),
+    B = 2: Winograd levels vs the plain cat_upsample2x + MIOpen path on the same weights, and
+    batch entries independent of their neighbours (what sharding over ranks relies on)."""
+    up = dms_amd.UpsamplingModule(1005, mode="bilinear", ker_size=3, amplification=32)
+    up.load_state_dict(det_fill_state(up.state_dict()))
+    up = up.to(DEV).eval()
+    gen = torch.Generator(device=DEV).manual_seed(7)
+    x = torch.randn((2, 1005, 16, 16), device=DEV, generator=gen)
+    feats = [torch.randn((2, c, s, s), device=DEV, generator=gen)
+             for c, s in ((64, 256), (336, 128), (704, 64), (1552, 32), (2688, 16))]
+    with torch.no_grad():
+        up.winograd = False
+        ref = up(x, feats)
+        up.winograd = "auto"
+        got = up(x, feats)
+        one = up(x[1:], [f[1:] for f in feats])
+        up.winograd = "f2"
+        got2 = up(x, feats)
+    assert got.shape == (2, 1, 512, 512)
+    assert rel_err(got, ref) < 5e-5 and rel_err(got2, ref) < 1e-5
+    assert rel_err(one, got[1:]) < 1e-5
+
+
 def test_sru_full_size_chunked_equals_whole_and_column_subset_oracle():
     """Config-5-like: T=4096, d=1000, k=3 (B reduced to 16 to bound memory/time).
     (i) splitting time in two calls with the carried c equals one call (recurrence
