@@ -109,6 +109,9 @@ class LaunchTimer(object):
         if name == "dmn_sru_state_fwd":
             T, B, d = args[4:7]
             return "sru_state (u0|f only) T=%d cols=%d" % (T, B * d), 8 * T * B * d
+        if name == "dmn_gconv3x3_bn_relu":
+            N, C, H, W = args[9:13]
+            return "dpn gconv3x3+2x(bn,relu) (all shapes)", 8 * N * C * H * W
         if name == "dmn_bn_relu":
             N, C, HW = args[5:8]
             return "dpn bn_relu (all shapes)", 8 * N * C * HW

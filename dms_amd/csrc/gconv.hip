@@ -1,0 +1,170 @@
+// dms_amd/csrc/gconv.hip -- grouped 3x3 convolution of the DPN blocks with its two BatchNorm+ReLU
+// neighbours fused in (inference, gfx950).
+//
+// DualPathBlock (dmn_pytorch/models/dpn/dpn_model.py:246-263) runs, between its two 1x1 convs,
+//     y = c3x3_b.conv( relu(c3x3_b.bn(x)) )          grouped, 32 groups of 3 / 6 / 12 / 24 channels
+//     z = relu(c1x1_c.bn(y))                         pre-activation of the next 1x1 conv
+// With 3..24 channels per group this convolution is a few hundred flops per output element:
+// it is HBM-bound (read x once, write z once), yet MIOpen's Winograd assembly kernel needs
+// 1.0 / 0.30 / 0.11 / 0.05 ms for the four DPN92 stages at B=32 where the traffic is worth
+// 0.08 / 0.04 / 0.02 / 0.01 ms (profiles/r1_miopen_fused_conv_probe.txt), and the two
+// BatchNorm+ReLU passes around it cost two more launches and two more round trips.
+//
+// One workgroup = one (image, group, spatial tile).  The tile's input channels are staged into
+// LDS a few at a time WITH the first BN+ReLU applied (zero outside the image: the conv pads the
+// activated tensor), the group's weights sit in LDS as [ci][tap][co] so that the CG output
+// channels of one (ci, tap) are one broadcast read; a lane owns 4 adjacent pixels x all CG
+// output channels in registers; the second BN+ReLU is applied to the accumulators.
+#include "common.h"
+
+namespace dmn {
+
+constexpr int GC_PX = 4;        // pixels per lane (along x)
+// input channels staged per LDS pass: a divisor of CG (6 for 6/12/24, 4 for 4/8/16/32, else CG)
+constexpr int gc_chunk(int cg) { return cg % 6 == 0 ? 6 : (cg % 4 == 0 ? 4 : cg); }
+
+template <int CG>
+__global__ void __launch_bounds__(256)
+gconv3x3_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                const float *__restrict__ m1, const float *__restrict__ s1, const float *__restrict__ b1,
+                const float *__restrict__ m2, const float *__restrict__ s2, const float *__restrict__ b2,
+                float *__restrict__ y, int C, int H, int W, int txn)
+{
+    constexpr int CH = gc_chunk(CG);
+    extern __shared__ float lds[];
+    const int tw = txn * GC_PX, th = 256 / txn;              // tile size in pixels
+    const int lw = tw + 2, lh = th + 2;                      // staged tile incl. halo
+    float *Wl = lds;                                         // [CG ci][9][CG co]
+    float *Xl = lds + CG * 9 * CG;                           // [CH][lh][lw]
+    const int tiles_x = (W + tw - 1) / tw;
+    const int x0 = (blockIdx.x % tiles_x) * tw, y0 = (blockIdx.x / tiles_x) * th;
+    const int g = blockIdx.y, n = blockIdx.z;
+    const int tid = threadIdx.x, tx = tid % txn, ty = tid / txn;
+    const int c0 = g * CG;
+
+    // weights of the group: w[(c0 + co), ci, tap] -> Wl[ci][tap][co]
+    for (int i = tid; i < CG * CG * 9; i += 256) {
+        const int co = i / (CG * 9), rem = i - co * CG * 9;      // rem = ci * 9 + tap
+        Wl[rem * CG + co] = w[(size_t)(c0 + co) * CG * 9 + rem];
+    }
+
+    float acc[CG][GC_PX];
+#pragma unroll
+    for (int co = 0; co < CG; ++co)
+#pragma unroll
+        for (int p = 0; p < GC_PX; ++p) acc[co][p] = 0.0f;
+
+    const float *xin = x + ((size_t)n * C + c0) * H * W;
+    for (int cb = 0; cb < CG; cb += CH) {
+        __syncthreads();                                     // previous chunk fully consumed
+        // 4 tile rows per pass, 64 lanes along x: coalesced row segments, no index divisions
+        for (int ci = 0; ci < CH; ++ci) {
+            const int c = c0 + cb + ci;
+            const float mm = m1 ? m1[c] : 0.0f, ss = m1 ? s1[c] : 1.0f, bb = m1 ? b1[c] : 0.0f;
+            const float *plane = xin + (size_t)(cb + ci) * H * W;
+            for (int ly = tid >> 6; ly < lh; ly += 4) {
+                const int gy = y0 + ly - 1;
+                const bool row_ok = gy >= 0 && gy < H;
+                for (int lx = tid & 63; lx < lw; lx += 64) {
+                    const int gx = x0 + lx - 1;
+                    float v = 0.0f;
+                    if (row_ok && gx >= 0 && gx < W) {
+                        v = plane[(size_t)gy * W + gx];
+                        if (m1) v = fmaxf(__builtin_fmaf(v - mm, ss, bb), 0.0f);
+                    }
+                    Xl[(ci * lh + ly) * lw + lx] = v;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int ci = 0; ci < CH; ++ci) {
+            float in[3][GC_PX + 2];
+            const float *xp = Xl + ((size_t)ci * lh + ty) * lw + tx * GC_PX;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int q = 0; q < GC_PX + 2; ++q) in[r][q] = xp[r * lw + q];
+            const float *wp = Wl + (size_t)(cb + ci) * 9 * CG;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dy = tap / 3, dx = tap - dy * 3;
+#pragma unroll
+                for (int co = 0; co < CG; ++co) {
+                    const float wv = wp[tap * CG + co];
+#pragma unroll
+                    for (int p = 0; p < GC_PX; ++p)
+                        acc[co][p] = __builtin_fmaf(wv, in[dy][p + dx], acc[co][p]);
+                }
+            }
+        }
+    }
+
+    const int oy = y0 + ty, ox = x0 + tx * GC_PX;
+    if (oy >= H || ox >= W) return;
+    float *yout = y + (((size_t)n * C + c0) * H + oy) * W + ox;
+    const bool vec = (W % 4 == 0);                           // ox % 4 == 0 by construction
+#pragma unroll
+    for (int co = 0; co < CG; ++co) {
+        float o[GC_PX];
+#pragma unroll
+        for (int p = 0; p < GC_PX; ++p) o[p] = acc[co][p];
+        if (m2) {
+            const float mm = m2[c0 + co], ss = s2[c0 + co], bb = b2[c0 + co];
+#pragma unroll
+            for (int p = 0; p < GC_PX; ++p) o[p] = fmaxf(__builtin_fmaf(o[p] - mm, ss, bb), 0.0f);
+        }
+        float *dst = yout + (size_t)co * H * W;
+        if (vec) {
+            *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+#pragma unroll
+            for (int p = 0; p < GC_PX; ++p)
+                if (ox + p < W) dst[p] = o[p];
+        }
+    }
+}
+
+}  // namespace dmn
+
+using namespace dmn;
+
+extern "C" int dmn_gconv3x3_bn_relu(const float *x, const float *w,
+                                    const float *mean1, const float *scale1, const float *bias1,
+                                    const float *mean2, const float *scale2, const float *bias2,
+                                    float *y, int N, int C, int H, int W, int groups, void *stream)
+{
+    if (!x || !w || !y) return fail(-1, "dmn_gconv3x3_bn_relu: NULL pointer");
+    if ((mean1 && (!scale1 || !bias1)) || (mean2 && (!scale2 || !bias2)))
+        return fail(-1, "dmn_gconv3x3_bn_relu: mean given without scale / bias");
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || groups <= 0 || C % groups)
+        return fail(-4, "dmn_gconv3x3_bn_relu: bad sizes N=%d C=%d H=%d W=%d groups=%d", N, C, H, W, groups);
+    if (N > 65535 || groups > 65535) return fail(-5, "dmn_gconv3x3_bn_relu: N or groups exceed the grid limits");
+    if (((uintptr_t)x | (uintptr_t)y) & 15) return fail(-7, "dmn_gconv3x3_bn_relu: x and y must be 16-byte aligned");
+    const int cg = C / groups;
+    // lanes across a tile row: 4 pixels each, at most 16 lanes (64 pixels), power of two
+    int txn = 1;
+    while (txn < 16 && txn * GC_PX < W) txn *= 2;
+    const int tw = txn * GC_PX, th = 256 / txn;
+    const int ch = gc_chunk(cg);
+    const size_t lds = ((size_t)cg * 9 * cg + (size_t)ch * (th + 2) * (tw + 2)) * sizeof(float);
+    dim3 grid(((W + tw - 1) / tw) * ((H + th - 1) / th), groups, N);
+    hipStream_t s = (hipStream_t)stream;
+#define DMN_GC(CG) hipLaunchKernelGGL((gconv3x3_kernel<CG>), grid, dim3(256), lds, s, x, w, mean1, scale1, bias1, \
+                                      mean2, scale2, bias2, y, C, H, W, txn)
+    switch (cg) {
+    case 3: DMN_GC(3); break;
+    case 4: DMN_GC(4); break;
+    case 6: DMN_GC(6); break;
+    case 8: DMN_GC(8); break;
+    case 12: DMN_GC(12); break;
+    case 16: DMN_GC(16); break;
+    case 24: DMN_GC(24); break;
+    case 32: DMN_GC(32); break;
+    default:
+        return fail(-5, "dmn_gconv3x3_bn_relu: %d channels per group not instantiated "
+                        "(3, 4, 6, 8, 12, 16, 24, 32)", cg);
+    }
+#undef DMN_GC
+    return launch_status("dmn_gconv3x3_bn_relu");
+}

@@ -111,6 +111,7 @@ class DualPathBlock(nn.Module):
         super().__init__()
         self.c1c, self.inc, self.b = c1c, inc, b
         self.kind = kind
+        self.fuse_gconv = True     # inference: own grouped 3x3 kernel with both BN+ReLU fused
         stride = 2 if kind == "down" else 1
         if kind == "down":
             self.c1x1_w_s2 = BnActConv2d(cin, c1c + 2 * inc, 1, 2)
@@ -152,8 +153,15 @@ class DualPathBlock(nn.Module):
             w = self.c1x1_w_s2 if self.kind == "down" else self.c1x1_w_s1
             base = _conv(w.conv, _bn_relu(w.bn, X))
         y = _conv(self.c1x1_a.conv, act_a)
-        y = self.c3x3_b.conv(_bn_relu(self.c3x3_b.bn, y))
-        y = _conv(self.c1x1_c.conv, _bn_relu(self.c1x1_c.bn, y))
+        conv_b = self.c3x3_b.conv
+        if (conv_b.stride == (1, 1) and self.fuse_gconv
+                and conv_b.in_channels // conv_b.groups in ops.GCONV_GROUP_WIDTHS):
+            # bn + relu, grouped 3x3 conv, next bn + relu: one HBM-bound pass
+            y = ops.gconv3x3_bn_relu(y, conv_b.weight.detach(), conv_b.groups,
+                                     _bn_consts(self.c3x3_b.bn), _bn_consts(self.c1x1_c.bn))
+        else:
+            y = _bn_relu(self.c1x1_c.bn, conv_b(_bn_relu(self.c3x3_b.bn, y)))
+        y = _conv(self.c1x1_c.conv, y)
         return ops.dpn_merge(base, y, self.c1c, _bn_consts(next_bn))
 
 

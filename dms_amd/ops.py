@@ -425,6 +425,27 @@ def bn_relu(x, mean, scale, bias):
     return y
 
 
+GCONV_GROUP_WIDTHS = (3, 4, 6, 8, 12, 16, 24, 32)
+
+
+def gconv3x3_bn_relu(x, weight, groups, bn_in=None, bn_out=None):
+    """relu(bn_out(conv3x3_grouped(relu(bn_in(x))))) in one pass; stride 1, pad 1, no bias.
+    bn_in / bn_out: (mean, scale, bias) or None to skip that stage."""
+    N, C, H, W = x.shape
+    _chk("gconv3x3_bn_relu", x)
+    _chk("gconv3x3_bn_relu", weight, (C, C // groups, 3, 3))
+    for bn in (bn_in, bn_out):
+        if bn is not None:
+            _chk_bn("gconv3x3_bn_relu", bn, C)
+    a = bn_in if bn_in is not None else (None, None, None)
+    b = bn_out if bn_out is not None else (None, None, None)
+    with torch.cuda.device(x.device):
+        y = torch.empty_like(x)
+        _lib.call("dmn_gconv3x3_bn_relu", _ptr(x), _ptr(weight), _ptr(a[0]), _ptr(a[1]), _ptr(a[2]),
+                  _ptr(b[0]), _ptr(b[1]), _ptr(b[2]), _ptr(y), N, C, H, W, int(groups), _stream())
+    return y
+
+
 def dpn_merge(base, y, c1c, bn=None):
     """out = [base[:, :c1c] + y[:, :c1c] | base[:, c1c:] | y[:, c1c:]] in one pass.
 

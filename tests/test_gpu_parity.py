@@ -503,6 +503,43 @@ def test_dpn_merge_matches_add_and_cat(N, Cb, Cy, c1c, H, W, with_bn):
         assert act is None
 
 
+@pytest.mark.parametrize("N,groups,cg,H,W", [(2, 4, 3, 8, 8), (1, 2, 6, 5, 7), (2, 32, 3, 16, 64), (1, 32, 12, 32, 32),
+                                             (2, 32, 24, 16, 16), (1, 3, 4, 9, 12), (1, 2, 8, 3, 3), (1, 2, 16, 6, 20),
+                                             (1, 1, 32, 4, 4), (1, 2, 3, 1, 1), (1, 4, 6, 20, 130)])
+@pytest.mark.parametrize("stages", ["both", "none", "in", "out"])
+def test_grouped_conv3x3_with_fused_bn_relu_matches_torch(N, groups, cg, H, W, stages):
+    C = groups * cg
+    x = det_uniform((N, C, H, W), 91, 2.0).to(DEV)
+    w = det_uniform((C, cg, 3, 3), 92, 0.5).to(DEV)
+
+    def consts(seed):
+        return (det_uniform((C,), seed, 1.0).to(DEV), det_uniform((C,), seed + 1, 1.0).to(DEV).abs() + 0.5,
+                det_uniform((C,), seed + 2, 0.5).to(DEV))
+
+    bn_in = consts(93) if stages in ("both", "in") else None
+    bn_out = consts(96) if stages in ("both", "out") else None
+
+    def bn_relu(t, bn):
+        m, sc, b = (v.view(1, -1, 1, 1).double() for v in bn)
+        return torch.relu((t - m) * sc + b)
+
+    t = x.double()
+    if bn_in is not None:
+        t = bn_relu(t, bn_in)
+    t = F.conv2d(t, w.double(), None, 1, 1, 1, groups)
+    if bn_out is not None:
+        t = bn_relu(t, bn_out)
+    got = ops.gconv3x3_bn_relu(x, w, groups, bn_in, bn_out)
+    assert got.shape == x.shape and rel_err(got, t.float()) < 1e-5
+
+
+def test_grouped_conv3x3_rejects_unsupported_group_width():
+    x = torch.zeros((1, 10, 4, 4), device=DEV)
+    w = torch.zeros((10, 5, 3, 3), device=DEV)
+    with pytest.raises(RuntimeError, match="not instantiated"):
+        ops.gconv3x3_bn_relu(x, w, 2)
+
+
 def test_dpn92_fused_glue_equals_plain_torch_backbone():
     """Same module, same weights: fast path (HIP glue) vs the plain torch path, all taps."""
     from dms_amd.models.dpn import DPN
