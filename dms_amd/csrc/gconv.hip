@@ -42,11 +42,8 @@ gconv3x3_kernel(const float *__restrict__ x, const float *__restrict__ w,
     const int tid = threadIdx.x, tx = tid % txn, ty = tid / txn;
     const int c0 = g * CG;
 
-    // weights of the group: w[(c0 + co), ci, tap] -> Wl[ci][tap][co]
-    for (int i = tid; i < CG * CG * 9; i += 256) {
-        const int co = i / (CG * 9), rem = i - co * CG * 9;      // rem = ci * 9 + tap
-        Wl[rem * CG + co] = w[(size_t)(c0 + co) * CG * 9 + rem];
-    }
+    // weights of the group, already [ci][tap][co]
+    for (int i = tid; i < CG * CG * 9; i += 256) Wl[i] = w[(size_t)g * CG * 9 * CG + i];
 
     float acc[CG][GC_PX];
 #pragma unroll
@@ -125,6 +122,141 @@ gconv3x3_kernel(const float *__restrict__ x, const float *__restrict__ w,
     }
 }
 
+// Fast path (W % 4 == 0): no LDS staging of the input and no barrier in the channel loop, so the
+// loads of successive channels overlap.  A lane reads its 4 pixels of the three rows as float4
+// (the rows overlap between vertical neighbours: L1 hits) and gets the two halo pixels from
+// its horizontal neighbours by wave shuffle; only tile-edge lanes load them.  SPLIT > 1: small
+// images (16 x 16 at the last DPN stage) would fill 64 of the 256 lanes, so the CG output
+// channels are split over SPLIT lane groups that share the same pixels.
+// Register budget: the kernel is HBM/latency-bound, so occupancy matters more than keeping every
+// weight and prefetched row in registers (unconstrained, hipcc used 188 VGPRs for CG = 3, i.e.
+// 2 waves per SIMD, and the kernel ran at 20 % of HBM bandwidth).
+template <int CG, int SPLIT>
+__global__ void __launch_bounds__(256)
+gconv3x3_rows_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                     const float *__restrict__ m1, const float *__restrict__ s1, const float *__restrict__ b1,
+                     const float *__restrict__ m2, const float *__restrict__ s2, const float *__restrict__ b2,
+                     float *__restrict__ y, int C, int H, int W, int txn)
+{
+    constexpr int COS = CG / SPLIT;                          // output channels per lane
+    constexpr int LANES = 256 / SPLIT;                       // pixel lanes (a multiple of 64)
+    const int tw = txn * GC_PX, th = LANES / txn;
+    const int tiles_x = (W + tw - 1) / tw;
+    const int x0 = (blockIdx.x % tiles_x) * tw, y0 = (blockIdx.x / tiles_x) * th;
+    const int g = blockIdx.y, n = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid % LANES;
+    // LANES is a multiple of 64, so `part` is wave-uniform: say so, the weight addresses below
+    // are then scalar and the weights arrive through the scalar cache straight into SGPR
+    // operands of the FMAs (no LDS stage, no VGPRs spent on weights)
+    const int part = __builtin_amdgcn_readfirstlane(tid / LANES);
+    const int tx = lane % txn, ty = lane / txn;
+    const int c0 = g * CG;
+    const float *wg = w + (size_t)g * CG * 9 * CG + part * COS;     // [ci][tap][co] of this group
+
+    const int oy = y0 + ty, ox = x0 + tx * GC_PX;
+    const bool col_ok = ox < W;                              // W % 4 == 0: whole float4 in or out
+    // Every load is UNCONDITIONAL on a clamped (always valid) address and invalid values are
+    // zeroed by a select afterwards: per-lane `if (ok) load` turns into one exec-masked block
+    // and one s_waitcnt per load, which serialises the loads' latencies.
+    const bool halo = tiles_x > 1;                           // uniform: tiles narrower than the image
+    const int oxc = col_ok ? ox : 0;
+    const int oxl = ox > 0 ? (ox - 1 < W ? ox - 1 : 0) : 0, oxr = ox + GC_PX < W ? ox + GC_PX : 0;
+    const bool l_ok = col_ok && ox > 0, r_ok = ox + GC_PX < W;
+    bool row_ok[3];
+    int row_off[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int gy = oy + r - 1;
+        row_ok[r] = gy >= 0 && gy < H;
+        row_off[r] = (gy < 0 ? 0 : (gy < H ? gy : H - 1)) * W;
+    }
+
+    float acc[COS][GC_PX];
+#pragma unroll
+    for (int co = 0; co < COS; ++co)
+#pragma unroll
+        for (int p = 0; p < GC_PX; ++p) acc[co][p] = 0.0f;
+
+    const float *xin = x + ((size_t)n * C + c0) * H * W;
+    // software pipeline over the input channels: the raw rows of channel ci + 1 are requested
+    // before channel ci is activated, shuffled and multiplied
+    struct Raw { float4 v[3]; float l[3], r[3]; };
+    auto load_raw = [&](int ci, Raw &R) {
+        const float *plane = xin + (size_t)ci * H * W;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            R.v[r] = *reinterpret_cast<const float4 *>(plane + row_off[r] + oxc);
+            if (halo) {
+                R.l[r] = plane[row_off[r] + oxl];
+                R.r[r] = plane[row_off[r] + oxr];
+            }
+        }
+    };
+    // one input row at a time: 6 activated pixels live, 3 * COS weights per row
+    auto consume = [&](const Raw &R, int ci) {
+        const int c = c0 + ci;
+        const float mm = m1 ? m1[c] : 0.0f, ss = m1 ? s1[c] : 1.0f, bb = m1 ? b1[c] : 0.0f;
+        const float *wp = wg + (size_t)ci * 9 * CG;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            float4 v = R.v[r];
+            float l = halo ? R.l[r] : 0.0f, rr = halo ? R.r[r] : 0.0f;
+            if (m1) {
+                v.x = fmaxf(__builtin_fmaf(v.x - mm, ss, bb), 0.0f);
+                v.y = fmaxf(__builtin_fmaf(v.y - mm, ss, bb), 0.0f);
+                v.z = fmaxf(__builtin_fmaf(v.z - mm, ss, bb), 0.0f);
+                v.w = fmaxf(__builtin_fmaf(v.w - mm, ss, bb), 0.0f);
+                l = fmaxf(__builtin_fmaf(l - mm, ss, bb), 0.0f);
+                rr = fmaxf(__builtin_fmaf(rr - mm, ss, bb), 0.0f);
+            }
+            const bool ok = row_ok[r] && col_ok;             // the conv pads the ACTIVATED tensor with zeros
+            v.x = ok ? v.x : 0.0f; v.y = ok ? v.y : 0.0f; v.z = ok ? v.z : 0.0f; v.w = ok ? v.w : 0.0f;
+            l = (halo && row_ok[r] && l_ok) ? l : 0.0f;
+            rr = (halo && row_ok[r] && r_ok) ? rr : 0.0f;
+            // halo from the horizontal neighbours (same wave: txn divides 64)
+            const float from_l = __shfl_up(v.w, 1), from_r = __shfl_down(v.x, 1);
+            const float in[GC_PX + 2] = {tx == 0 ? l : from_l, v.x, v.y, v.z, v.w,
+                                         tx == txn - 1 ? rr : from_r};
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+#pragma unroll
+                for (int co = 0; co < COS; ++co) {
+                    const float wv = wp[(r * 3 + dx) * CG + co];
+#pragma unroll
+                    for (int p = 0; p < GC_PX; ++p)
+                        acc[co][p] = __builtin_fmaf(wv, in[p + dx], acc[co][p]);
+                }
+            }
+        }
+    };
+    Raw ra, rb;
+    load_raw(0, ra);
+#pragma unroll 1
+    for (int ci = 0; ci + 1 < CG; ci += 2) {
+        load_raw(ci + 1, rb);
+        consume(ra, ci);
+        if (ci + 2 < CG) load_raw(ci + 2, ra);
+        consume(rb, ci + 1);
+    }
+    if constexpr (CG % 2 == 1) consume(ra, CG - 1);
+
+    if (oy >= H || !col_ok) return;
+    float *yout = y + (((size_t)n * C + c0 + part * COS) * H + oy) * W + ox;
+#pragma unroll
+    for (int co = 0; co < COS; ++co) {
+        float o[GC_PX];
+#pragma unroll
+        for (int p = 0; p < GC_PX; ++p) o[p] = acc[co][p];
+        if (m2) {
+            const int c = c0 + part * COS + co;
+            const float mm = m2[c], ss = s2[c], bb = b2[c];
+#pragma unroll
+            for (int p = 0; p < GC_PX; ++p) o[p] = fmaxf(__builtin_fmaf(o[p] - mm, ss, bb), 0.0f);
+        }
+        *reinterpret_cast<float4 *>(yout + (size_t)co * H * W) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 }  // namespace dmn
 
 using namespace dmn;
@@ -142,14 +274,44 @@ extern "C" int dmn_gconv3x3_bn_relu(const float *x, const float *w,
     if (N > 65535 || groups > 65535) return fail(-5, "dmn_gconv3x3_bn_relu: N or groups exceed the grid limits");
     if (((uintptr_t)x | (uintptr_t)y) & 15) return fail(-7, "dmn_gconv3x3_bn_relu: x and y must be 16-byte aligned");
     const int cg = C / groups;
-    // lanes across a tile row: 4 pixels each, at most 16 lanes (64 pixels), power of two
+    // lanes across a tile row: 4 pixels each, power of two, at most 32 lanes (128 pixels: whole
+    // rows for every DPN stage, so a tile is one contiguous run of memory per channel)
     int txn = 1;
-    while (txn < 16 && txn * GC_PX < W) txn *= 2;
+    while (txn < 32 && txn * GC_PX < W) txn *= 2;
     const int tw = txn * GC_PX, th = 256 / txn;
     const int ch = gc_chunk(cg);
     const size_t lds = ((size_t)cg * 9 * cg + (size_t)ch * (th + 2) * (tw + 2)) * sizeof(float);
     dim3 grid(((W + tw - 1) / tw) * ((H + th - 1) / th), groups, N);
     hipStream_t s = (hipStream_t)stream;
+    if (W % 4 == 0) {
+        // fast path; output channels split over 4 lane groups when the image fills <= 64 lanes
+        // ... or when there are too few whole-group workgroups to fill the chip (small batches)
+        const long long wgs = (long long)((W + tw - 1) / tw) * ((H + th - 1) / th) * groups * N;
+        const bool split = cg % 4 == 0 && cg >= 12 && (txn * H <= 64 || wgs < 2 * NUM_CU);
+        const int lanes = split ? 64 : 256;
+        const int th2 = lanes / txn;
+        const size_t ldsw = 0;
+        dim3 grid2(((W + tw - 1) / tw) * ((H + th2 - 1) / th2), groups, N);
+#define DMN_GR(CG, SP) hipLaunchKernelGGL((gconv3x3_rows_kernel<CG, SP>), grid2, dim3(256), ldsw, s, x, w, mean1, \
+                                          scale1, bias1, mean2, scale2, bias2, y, C, H, W, txn)
+#define DMN_GRS(CG) do { if (split) DMN_GR(CG, 4); else DMN_GR(CG, 1); } while (0)
+        switch (cg) {
+        case 3: DMN_GR(3, 1); break;
+        case 4: DMN_GR(4, 1); break;
+        case 6: DMN_GR(6, 1); break;
+        case 8: DMN_GR(8, 1); break;
+        case 12: DMN_GRS(12); break;
+        case 16: DMN_GRS(16); break;
+        case 24: DMN_GRS(24); break;
+        case 32: DMN_GRS(32); break;
+        default:
+            return fail(-5, "dmn_gconv3x3_bn_relu: %d channels per group not instantiated "
+                            "(3, 4, 6, 8, 12, 16, 24, 32)", cg);
+        }
+#undef DMN_GRS
+#undef DMN_GR
+        return launch_status("dmn_gconv3x3_bn_relu");
+    }
 #define DMN_GC(CG) hipLaunchKernelGGL((gconv3x3_kernel<CG>), grid, dim3(256), lds, s, x, w, mean1, scale1, bias1, \
                                       mean2, scale2, bias2, y, C, H, W, txn)
     switch (cg) {

@@ -57,6 +57,17 @@ def _bn_consts(bn):
     return cached[1]
 
 
+def _gconv_weight(conv):
+    """Grouped conv weight in the kernel's (groups, ci, 9, co) layout, cached per weight version."""
+    w = conv.weight
+    key = (w._version, w.data_ptr())
+    cached = conv.__dict__.get("_dmn_gconv_w")
+    if cached is None or cached[0] != key:
+        cached = (key, ops.gconv_weight_layout(w, conv.groups))
+        conv.__dict__["_dmn_gconv_w"] = cached
+    return cached[1]
+
+
 def _bn_relu(bn, x):
     return ops.bn_relu(x, *_bn_consts(bn))
 
@@ -157,7 +168,7 @@ class DualPathBlock(nn.Module):
         if (conv_b.stride == (1, 1) and self.fuse_gconv
                 and conv_b.in_channels // conv_b.groups in ops.GCONV_GROUP_WIDTHS):
             # bn + relu, grouped 3x3 conv, next bn + relu: one HBM-bound pass
-            y = ops.gconv3x3_bn_relu(y, conv_b.weight.detach(), conv_b.groups,
+            y = ops.gconv3x3_bn_relu(y, _gconv_weight(conv_b), conv_b.groups,
                                      _bn_consts(self.c3x3_b.bn), _bn_consts(self.c1x1_c.bn))
         else:
             y = _bn_relu(self.c1x1_c.bn, conv_b(_bn_relu(self.c3x3_b.bn, y)))

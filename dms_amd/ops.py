@@ -428,12 +428,21 @@ def bn_relu(x, mean, scale, bias):
 GCONV_GROUP_WIDTHS = (3, 4, 6, 8, 12, 16, 24, 32)
 
 
-def gconv3x3_bn_relu(x, weight, groups, bn_in=None, bn_out=None):
+def gconv_weight_layout(weight, groups):
+    """(C, C/groups, 3, 3) conv weight -> (groups, ci, 9, co): the layout dmn_gconv3x3_bn_relu
+    reads (the co of one (ci, tap) adjacent, so they arrive as one scalar load)."""
+    C, cg = weight.shape[:2]
+    return weight.detach().reshape(groups, cg, cg, 9).permute(0, 2, 3, 1).contiguous()
+
+
+def gconv3x3_bn_relu(x, weight_t, groups, bn_in=None, bn_out=None):
     """relu(bn_out(conv3x3_grouped(relu(bn_in(x))))) in one pass; stride 1, pad 1, no bias.
-    bn_in / bn_out: (mean, scale, bias) or None to skip that stage."""
+    weight_t: gconv_weight_layout(conv.weight, groups); bn_in / bn_out: (mean, scale, bias) or
+    None to skip that stage."""
     N, C, H, W = x.shape
     _chk("gconv3x3_bn_relu", x)
-    _chk("gconv3x3_bn_relu", weight, (C, C // groups, 3, 3))
+    weight = weight_t
+    _chk("gconv3x3_bn_relu", weight, (groups, C // groups, 9, C // groups))
     for bn in (bn_in, bn_out):
         if bn is not None:
             _chk_bn("gconv3x3_bn_relu", bn, C)

@@ -205,7 +205,9 @@ int dmn_threshold_iou(const float *prob, const float *mask, const float *thresho
  * the BatchNorm+ReLU before it and the one after it fused in (dpn_model.py:246-263:
  * `c3x3_b` = BnActConv2d, followed by `c1x1_c`'s bn + act), inference:
  *   y = relu(bn2( conv3x3_grouped( relu(bn1(x)) ) ))
- *   x, y (N, C, H, W) 16-byte aligned; w (C, C/groups, 3, 3) no bias; C/groups in {3,4,6,8,12,16,24,32}
+ *   x, y (N, C, H, W) 16-byte aligned; C/groups = cg in {3,4,6,8,12,16,24,32}; no bias
+ *   w (groups, cg_in, 9, cg_out): the reference's (C, cg, 3, 3) weight permuted once per weight
+ *   version by the caller, so that the output channels of one (ci, tap) are adjacent
  *   (mean1, scale1, bias1) / (mean2, scale2, bias2): (C) each as in dmn_bn_relu, or all NULL
  *   to skip that stage.
  */

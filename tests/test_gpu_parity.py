@@ -529,13 +529,13 @@ def test_grouped_conv3x3_with_fused_bn_relu_matches_torch(N, groups, cg, H, W, s
     t = F.conv2d(t, w.double(), None, 1, 1, 1, groups)
     if bn_out is not None:
         t = bn_relu(t, bn_out)
-    got = ops.gconv3x3_bn_relu(x, w, groups, bn_in, bn_out)
+    got = ops.gconv3x3_bn_relu(x, ops.gconv_weight_layout(w, groups), groups, bn_in, bn_out)
     assert got.shape == x.shape and rel_err(got, t.float()) < 1e-5
 
 
 def test_grouped_conv3x3_rejects_unsupported_group_width():
     x = torch.zeros((1, 10, 4, 4), device=DEV)
-    w = torch.zeros((10, 5, 3, 3), device=DEV)
+    w = torch.zeros((2, 5, 9, 5), device=DEV)
     with pytest.raises(RuntimeError, match="not instantiated"):
         ops.gconv3x3_bn_relu(x, w, 2)
 
