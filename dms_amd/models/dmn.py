@@ -117,7 +117,7 @@ class BaseDMN(nn.Module):
                 and self.mrnn.rnn_lst[0].k == 4)
         if fold:
             Wv_f, Wl_f, Wp_f, b_f = self._folded_weights()
-            A = torch.matmul(V.transpose(1, 2), Wv_f)               # (B, S, 4*Hm)
+            A = ops.tuned_matmul(V.transpose(1, 2), Wv_f)           # (B, S, 4*Hm)
             Bt = torch.addmm(b_f, lang_cat, Wl_f).view(L, B, -1)    # (L, B, 4*Hm)
             U0 = ops.mix_bcast_add(A, Bt, P, Wp_f)                  # (S*L, B, 4*Hm) = layer-0 U
             out, _ = self.mrnn(U0, tail=S, projected=True)

@@ -71,10 +71,11 @@ class SRUCell(nn.Module):
         columns (2 of k: a third less GEMM work for k = 3) and run through the state-only scan."""
         T, B, n_in = x.shape
         head = x[:h_t0].reshape(h_t0 * B, n_in)
-        u2 = head.mm(self._state_weight()).view(h_t0, B, self.n_out, 2)
+        u2 = ops.tuned_matmul(head, self._state_weight()).view(h_t0, B, self.n_out, 2)
         c_mid = ops.sru_state(u2, self.bias, c0)
         tail = x[h_t0:]
-        u = tail.reshape((T - h_t0) * B, n_in).mm(self.weight).view(T - h_t0, B, self.n_out, self.k)
+        u = ops.tuned_matmul(tail.reshape((T - h_t0) * B, n_in), self.weight).view(
+            T - h_t0, B, self.n_out, self.k)
         return ops.sru_compute(u, tail if self.k == 3 else None, self.bias, c_mid,
                                self.activation, self.scale_x, 0)
 
@@ -90,7 +91,11 @@ class SRUCell(nn.Module):
             or (c0 is not None and c0.requires_grad))
         if 0 < h_t0 < T and not needs_grad and self.state_only_head:
             return self._forward_tail(x, c0, h_t0)
-        u = x.view(T * B, n_in).mm(self.weight).view(T, B, self.n_out, self.k)
+        if needs_grad:
+            u = x.view(T * B, n_in).mm(self.weight)
+        else:                                   # inference: BLAS library chosen per shape
+            u = ops.tuned_matmul(x.view(T * B, n_in), self.weight)
+        u = u.view(T, B, self.n_out, self.k)
         return ops.sru_compute(u, x if self.k == 3 else None, self.bias, c0,
                                self.activation, self.scale_x, h_t0)
 
