@@ -111,7 +111,8 @@ class LaunchTimer(object):
             return "sru_state (u0|f only) T=%d cols=%d" % (T, B * d), 8 * T * B * d
         if name == "dmn_gconv3x3_bn_relu":
             N, C, H, W = args[9:13]
-            return "dpn gconv3x3+2x(bn,relu) (all shapes)", 8 * N * C * H * W
+            st = args[14]
+            return "dpn gconv3x3+2x(bn,relu) (all shapes)", 4 * N * C * H * W * (st * st + 1) // (st * st)
         if name == "dmn_bn_relu":
             N, C, HW = args[5:8]
             return "dpn bn_relu (all shapes)", 8 * N * C * HW

@@ -34,7 +34,7 @@ SIGNATURES = {
     "dmn_wino_cat_upsample2x_transform": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "dmn_wino_output_transform": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
     "dmn_threshold_iou": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
-    "dmn_gconv3x3_bn_relu": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "dmn_gconv3x3_bn_relu": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "dmn_bn_relu": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
     "dmn_dpn_merge": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
 }

@@ -257,6 +257,120 @@ gconv3x3_rows_kernel(const float *__restrict__ x, const float *__restrict__ w,
     }
 }
 
+// Stride 2 (the first block of DPN stages 3-5): same structure in OUTPUT coordinates.  A lane's 4
+// output pixels ox .. ox+3 read input columns 2ox-1 .. 2ox+7: two float4 plus one halo pixel
+// from the left neighbour; input rows 2oy-1 .. 2oy+1.  Needs H % 2 == 0 and W % 8 == 0.
+template <int CG, int SPLIT>
+__global__ void __launch_bounds__(256)
+gconv3x3_s2_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                   const float *__restrict__ m1, const float *__restrict__ s1, const float *__restrict__ b1,
+                   const float *__restrict__ m2, const float *__restrict__ s2, const float *__restrict__ b2,
+                   float *__restrict__ y, int C, int H, int W, int txn)
+{
+    constexpr int COS = CG / SPLIT;
+    constexpr int LANES = 256 / SPLIT;
+    const int Ho = H / 2, Wo = W / 2;
+    const int tw = txn * GC_PX, th = LANES / txn;            // tile in output pixels
+    const int tiles_x = (Wo + tw - 1) / tw;
+    const int x0 = (blockIdx.x % tiles_x) * tw, y0 = (blockIdx.x / tiles_x) * th;
+    const int g = blockIdx.y, n = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid % LANES;
+    const int part = __builtin_amdgcn_readfirstlane(tid / LANES);
+    const int tx = lane % txn, ty = lane / txn;
+    const int c0 = g * CG;
+    const float *wg = w + (size_t)g * CG * 9 * CG + part * COS;
+
+    const int oy = y0 + ty, ox = x0 + tx * GC_PX;
+    const bool col_ok = ox < Wo;
+    const bool halo = tiles_x > 1;
+    const int ixc = col_ok ? 2 * ox : 0;                     // first input column of the lane
+    const int ixl = (col_ok && ox > 0) ? 2 * ox - 1 : 0;
+    const bool l_ok = col_ok && ox > 0;
+    bool row_ok[3];
+    int row_off[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int gy = 2 * oy + r - 1;
+        row_ok[r] = gy >= 0 && gy < H;
+        row_off[r] = (gy < 0 ? 0 : (gy < H ? gy : H - 1)) * W;
+    }
+
+    float acc[COS][GC_PX];
+#pragma unroll
+    for (int co = 0; co < COS; ++co)
+#pragma unroll
+        for (int p = 0; p < GC_PX; ++p) acc[co][p] = 0.0f;
+
+    const float *xin = x + ((size_t)n * C + c0) * H * W;
+    struct Raw { float4 a[3], b[3]; float l[3]; };
+    auto load_raw = [&](int ci, Raw &R) {
+        const float *plane = xin + (size_t)ci * H * W;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            R.a[r] = *reinterpret_cast<const float4 *>(plane + row_off[r] + ixc);
+            R.b[r] = *reinterpret_cast<const float4 *>(plane + row_off[r] + ixc + 4);
+            if (halo) R.l[r] = plane[row_off[r] + ixl];
+        }
+    };
+    auto consume = [&](const Raw &R, int ci) {
+        const int c = c0 + ci;
+        const float mm = m1 ? m1[c] : 0.0f, ss = m1 ? s1[c] : 1.0f, bb = m1 ? b1[c] : 0.0f;
+        const float *wp = wg + (size_t)ci * 9 * CG;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            float v[8] = {R.a[r].x, R.a[r].y, R.a[r].z, R.a[r].w, R.b[r].x, R.b[r].y, R.b[r].z, R.b[r].w};
+            float l = halo ? R.l[r] : 0.0f;
+            const bool ok = row_ok[r] && col_ok;
+            if (m1) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = fmaxf(__builtin_fmaf(v[q] - mm, ss, bb), 0.0f);
+                l = fmaxf(__builtin_fmaf(l - mm, ss, bb), 0.0f);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = ok ? v[q] : 0.0f;
+            l = (halo && row_ok[r] && l_ok) ? l : 0.0f;
+            const float from_l = __shfl_up(v[7], 1);
+            const float in[9] = {tx == 0 ? l : from_l, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+#pragma unroll
+                for (int co = 0; co < COS; ++co) {
+                    const float wv = wp[(r * 3 + dx) * CG + co];
+#pragma unroll
+                    for (int p = 0; p < GC_PX; ++p)
+                        acc[co][p] = __builtin_fmaf(wv, in[2 * p + dx], acc[co][p]);
+                }
+            }
+        }
+    };
+    Raw ra, rb;
+    load_raw(0, ra);
+#pragma unroll 1
+    for (int ci = 0; ci + 1 < CG; ci += 2) {
+        load_raw(ci + 1, rb);
+        consume(ra, ci);
+        if (ci + 2 < CG) load_raw(ci + 2, ra);
+        consume(rb, ci + 1);
+    }
+    if constexpr (CG % 2 == 1) consume(ra, CG - 1);
+
+    if (oy >= Ho || !col_ok) return;
+    float *yout = y + (((size_t)n * C + c0 + part * COS) * Ho + oy) * Wo + ox;
+#pragma unroll
+    for (int co = 0; co < COS; ++co) {
+        float o[GC_PX];
+#pragma unroll
+        for (int p = 0; p < GC_PX; ++p) o[p] = acc[co][p];
+        if (m2) {
+            const int c = c0 + part * COS + co;
+            const float mm = m2[c], ss = s2[c], bb = b2[c];
+#pragma unroll
+            for (int p = 0; p < GC_PX; ++p) o[p] = fmaxf(__builtin_fmaf(o[p] - mm, ss, bb), 0.0f);
+        }
+        *reinterpret_cast<float4 *>(yout + (size_t)co * Ho * Wo) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 }  // namespace dmn
 
 using namespace dmn;
@@ -264,9 +378,11 @@ using namespace dmn;
 extern "C" int dmn_gconv3x3_bn_relu(const float *x, const float *w,
                                     const float *mean1, const float *scale1, const float *bias1,
                                     const float *mean2, const float *scale2, const float *bias2,
-                                    float *y, int N, int C, int H, int W, int groups, void *stream)
+                                    float *y, int N, int C, int H, int W, int groups, int stride,
+                                    void *stream)
 {
     if (!x || !w || !y) return fail(-1, "dmn_gconv3x3_bn_relu: NULL pointer");
+    if (stride != 1 && stride != 2) return fail(-2, "dmn_gconv3x3_bn_relu: stride must be 1 or 2 (got %d)", stride);
     if ((mean1 && (!scale1 || !bias1)) || (mean2 && (!scale2 || !bias2)))
         return fail(-1, "dmn_gconv3x3_bn_relu: mean given without scale / bias");
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || groups <= 0 || C % groups)
@@ -274,6 +390,37 @@ extern "C" int dmn_gconv3x3_bn_relu(const float *x, const float *w,
     if (N > 65535 || groups > 65535) return fail(-5, "dmn_gconv3x3_bn_relu: N or groups exceed the grid limits");
     if (((uintptr_t)x | (uintptr_t)y) & 15) return fail(-7, "dmn_gconv3x3_bn_relu: x and y must be 16-byte aligned");
     const int cg = C / groups;
+    if (stride == 2) {
+        if (H % 2 || W % 8) return fail(-4, "dmn_gconv3x3_bn_relu: stride 2 needs H %% 2 == 0 and W %% 8 == 0 (got %dx%d)", H, W);
+        const int Ho = H / 2, Wo = W / 2;
+        int txo = 1;
+        while (txo < 32 && txo * GC_PX < Wo) txo *= 2;
+        const int two = txo * GC_PX;
+        const long long wgs1 = (long long)((Wo + two - 1) / two) * ((Ho + 256 / txo - 1) / (256 / txo)) * groups * N;
+        const bool split2 = cg % 4 == 0 && cg >= 12 && (txo * Ho <= 64 || wgs1 < 2 * NUM_CU);
+        const int tho = (split2 ? 64 : 256) / txo;
+        dim3 grid3(((Wo + two - 1) / two) * ((Ho + tho - 1) / tho), groups, N);
+        hipStream_t s2 = (hipStream_t)stream;
+#define DMN_G2(CG, SP) hipLaunchKernelGGL((gconv3x3_s2_kernel<CG, SP>), grid3, dim3(256), 0, s2, x, w, mean1, \
+                                          scale1, bias1, mean2, scale2, bias2, y, C, H, W, txo)
+#define DMN_G2S(CG) do { if (split2) DMN_G2(CG, 4); else DMN_G2(CG, 1); } while (0)
+        switch (cg) {
+        case 3: DMN_G2(3, 1); break;
+        case 4: DMN_G2(4, 1); break;
+        case 6: DMN_G2(6, 1); break;
+        case 8: DMN_G2(8, 1); break;
+        case 12: DMN_G2S(12); break;
+        case 16: DMN_G2S(16); break;
+        case 24: DMN_G2S(24); break;
+        case 32: DMN_G2S(32); break;
+        default:
+            return fail(-5, "dmn_gconv3x3_bn_relu: %d channels per group not instantiated "
+                            "(3, 4, 6, 8, 12, 16, 24, 32)", cg);
+        }
+#undef DMN_G2S
+#undef DMN_G2
+        return launch_status("dmn_gconv3x3_bn_relu");
+    }
     // lanes across a tile row: 4 pixels each, power of two, at most 32 lanes (128 pixels: whole
     // rows for every DPN stage, so a tile is one contiguous run of memory per channel)
     int txn = 1;

@@ -165,11 +165,12 @@ class DualPathBlock(nn.Module):
             base = _conv(w.conv, _bn_relu(w.bn, X))
         y = _conv(self.c1x1_a.conv, act_a)
         conv_b = self.c3x3_b.conv
-        if (conv_b.stride == (1, 1) and self.fuse_gconv
-                and conv_b.in_channels // conv_b.groups in ops.GCONV_GROUP_WIDTHS):
+        stride = conv_b.stride[0]
+        if (self.fuse_gconv and conv_b.in_channels // conv_b.groups in ops.GCONV_GROUP_WIDTHS
+                and (stride == 1 or (stride == 2 and y.shape[2] % 2 == 0 and y.shape[3] % 8 == 0))):
             # bn + relu, grouped 3x3 conv, next bn + relu: one HBM-bound pass
             y = ops.gconv3x3_bn_relu(y, _gconv_weight(conv_b), conv_b.groups,
-                                     _bn_consts(self.c3x3_b.bn), _bn_consts(self.c1x1_c.bn))
+                                     _bn_consts(self.c3x3_b.bn), _bn_consts(self.c1x1_c.bn), stride)
         else:
             y = _bn_relu(self.c1x1_c.bn, conv_b(_bn_relu(self.c3x3_b.bn, y)))
         y = _conv(self.c1x1_c.conv, y)

@@ -435,8 +435,8 @@ def gconv_weight_layout(weight, groups):
     return weight.detach().reshape(groups, cg, cg, 9).permute(0, 2, 3, 1).contiguous()
 
 
-def gconv3x3_bn_relu(x, weight_t, groups, bn_in=None, bn_out=None):
-    """relu(bn_out(conv3x3_grouped(relu(bn_in(x))))) in one pass; stride 1, pad 1, no bias.
+def gconv3x3_bn_relu(x, weight_t, groups, bn_in=None, bn_out=None, stride=1):
+    """relu(bn_out(conv3x3_grouped(relu(bn_in(x))))) in one pass; stride 1 or 2, pad 1, no bias.
     weight_t: gconv_weight_layout(conv.weight, groups); bn_in / bn_out: (mean, scale, bias) or
     None to skip that stage."""
     N, C, H, W = x.shape
@@ -449,9 +449,10 @@ def gconv3x3_bn_relu(x, weight_t, groups, bn_in=None, bn_out=None):
     a = bn_in if bn_in is not None else (None, None, None)
     b = bn_out if bn_out is not None else (None, None, None)
     with torch.cuda.device(x.device):
-        y = torch.empty_like(x)
+        y = torch.empty((N, C, H // stride, W // stride), device=x.device, dtype=torch.float32)
         _lib.call("dmn_gconv3x3_bn_relu", _ptr(x), _ptr(weight), _ptr(a[0]), _ptr(a[1]), _ptr(a[2]),
-                  _ptr(b[0]), _ptr(b[1]), _ptr(b[2]), _ptr(y), N, C, H, W, int(groups), _stream())
+                  _ptr(b[0]), _ptr(b[1]), _ptr(b[2]), _ptr(y), N, C, H, W, int(groups), int(stride),
+                  _stream())
     return y
 
 

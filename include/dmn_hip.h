@@ -201,11 +201,11 @@ int dmn_threshold_iou(const float *prob, const float *mask, const float *thresho
  *   BatchNorm (the following block's c1x1_a.bn, or conv5_bn_ac), written in the same pass.
  */
 /*
- * dmn_gconv3x3_bn_relu: the grouped 3x3 / stride-1 / pad-1 convolution of a DualPathBlock with
+ * dmn_gconv3x3_bn_relu: the grouped 3x3 / pad-1 convolution (stride 1 or 2) of a DualPathBlock with
  * the BatchNorm+ReLU before it and the one after it fused in (dpn_model.py:246-263:
  * `c3x3_b` = BnActConv2d, followed by `c1x1_c`'s bn + act), inference:
  *   y = relu(bn2( conv3x3_grouped( relu(bn1(x)) ) ))
- *   x, y (N, C, H, W) 16-byte aligned; C/groups = cg in {3,4,6,8,12,16,24,32}; no bias
+ *   x (N, C, H, W), y (N, C, H/stride, W/stride) 16-byte aligned (stride 2: H % 2 == 0, W % 8 == 0); C/groups = cg in {3,4,6,8,12,16,24,32}; no bias
  *   w (groups, cg_in, 9, cg_out): the reference's (C, cg, 3, 3) weight permuted once per weight
  *   version by the caller, so that the output channels of one (ci, tap) are adjacent
  *   (mean1, scale1, bias1) / (mean2, scale2, bias2): (C) each as in dmn_bn_relu, or all NULL
@@ -214,7 +214,7 @@ int dmn_threshold_iou(const float *prob, const float *mask, const float *thresho
 int dmn_gconv3x3_bn_relu(const float *x, const float *w,
                          const float *mean1, const float *scale1, const float *bias1,
                          const float *mean2, const float *scale2, const float *bias2,
-                         float *y, int N, int C, int H, int W, int groups, void *stream);
+                         float *y, int N, int C, int H, int W, int groups, int stride, void *stream);
 int dmn_bn_relu(const float *x, const float *mean, const float *scale, const float *bias,
                 float *y, int N, int C, int HW, void *stream);
 int dmn_dpn_merge(const float *base, const float *yv, float *out, float *act,

@@ -533,6 +533,26 @@ def test_grouped_conv3x3_with_fused_bn_relu_matches_torch(N, groups, cg, H, W, s
     assert got.shape == x.shape and rel_err(got, t.float()) < 1e-5
 
 
+@pytest.mark.parametrize("N,groups,cg,H,W", [(2, 4, 3, 8, 8), (1, 32, 6, 16, 64), (2, 32, 12, 32, 32), (1, 8, 24, 32, 32),
+                                             (1, 2, 4, 6, 24), (1, 2, 16, 2, 8), (1, 2, 6, 20, 272)])
+def test_grouped_conv3x3_stride2_matches_torch(N, groups, cg, H, W):
+    C = groups * cg
+    x = det_uniform((N, C, H, W), 101, 2.0).to(DEV)
+    w = det_uniform((C, cg, 3, 3), 102, 0.5).to(DEV)
+    bn1 = (det_uniform((C,), 103, 1.0).to(DEV), det_uniform((C,), 104, 1.0).to(DEV).abs() + 0.5, det_uniform((C,), 105, 0.5).to(DEV))
+    bn2 = (det_uniform((C,), 106, 1.0).to(DEV), det_uniform((C,), 107, 1.0).to(DEV).abs() + 0.5, det_uniform((C,), 108, 0.5).to(DEV))
+
+    def bn_relu(t, bn):
+        m, sc, b = (v.view(1, -1, 1, 1).double() for v in bn)
+        return torch.relu((t - m) * sc + b)
+
+    want = bn_relu(F.conv2d(bn_relu(x.double(), bn1), w.double(), None, 2, 1, 1, groups), bn2).float()
+    got = ops.gconv3x3_bn_relu(x, ops.gconv_weight_layout(w, groups), groups, bn1, bn2, stride=2)
+    assert got.shape == want.shape and rel_err(got, want) < 1e-5
+    with pytest.raises(RuntimeError, match="stride 2 needs"):
+        ops.gconv3x3_bn_relu(x[:, :, :, :W - 4].contiguous(), ops.gconv_weight_layout(w, groups), groups, bn1, bn2, stride=2)
+
+
 def test_grouped_conv3x3_rejects_unsupported_group_width():
     x = torch.zeros((1, 10, 4, 4), device=DEV)
     w = torch.zeros((2, 5, 9, 5), device=DEV)
