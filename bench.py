@@ -113,6 +113,12 @@ class LaunchTimer(object):
             N, C, H, W = args[9:13]
             st = args[14]
             return "dpn gconv3x3+2x(bn,relu) (all shapes)", 4 * N * C * H * W * (st * st + 1) // (st * st)
+        if name == "dmn_bn_relu_s2":
+            N, C, H, W = args[5:9]
+            return "dpn bn_relu stride 2", 4 * N * C * H * W * 3 // 4
+        if name == "dmn_channel_dot":
+            N, C, HW = args[4:7]
+            return "channel_dot C=%d" % C, 4 * N * HW * (C + 1)
         if name == "dmn_bn_relu":
             N, C, HW = args[5:8]
             return "dpn bn_relu (all shapes)", 8 * N * C * HW

@@ -89,6 +89,60 @@ dpn_merge_kernel(const float *__restrict__ base, const float *__restrict__ yv,
     }
 }
 
+// y[n,c,oy,ox] = relu(bn(x[n,c,2oy,2ox])): the pre-activation of a stride-2 1x1 projection only
+// needs every other row and column.  One lane = 2 adjacent outputs (one float4 of input).
+__global__ void __launch_bounds__(256)
+bn_relu_s2_kernel(const float *__restrict__ x, const float *__restrict__ mean,
+                  const float *__restrict__ scale, const float *__restrict__ bias,
+                  float *__restrict__ y, long long total, int C, int Ho, int Wo2, int W)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int xo = (int)(i % Wo2);
+        const long long t = i / Wo2;
+        const int oy = (int)(t % Ho);
+        const long long pl = t / Ho;                               // n * C + c
+        const int c = (int)(pl % C);
+        const float m = mean[c], s = scale[c], b = bias[c];
+        const float4 v = *reinterpret_cast<const float4 *>(x + (pl * 2 * Ho + 2 * oy) * W + 4 * xo);
+        float2 o;
+        o.x = fmaxf(__builtin_fmaf(v.x - m, s, b), 0.0f);
+        o.y = fmaxf(__builtin_fmaf(v.z - m, s, b), 0.0f);
+        *reinterpret_cast<float2 *>(y + (pl * Ho + oy) * (2 * Wo2) + 2 * xo) = o;
+    }
+}
+
+// out[n,p] = sum_c w[c] * x[n,c,p] + bias0: a 1x1 convolution to ONE channel (the head's out_layer,
+// dmn.py:327,341, and output_collapse, dmn.py:213) is a channel reduction that reads x once.
+template <int VEC>
+__global__ void __launch_bounds__(256)
+channel_dot_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                   const float *__restrict__ bias0, float *__restrict__ out,
+                   long long total, int C, int HWv)
+{
+    const float b0 = bias0 ? bias0[0] : 0.0f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int p = (int)(i % HWv);
+        const long long n = i / HWv;
+        float a0 = b0, a1 = b0, a2 = b0, a3 = b0;
+        const float *xp = x + (n * C * HWv + p) * VEC;
+#pragma unroll 8
+        for (int c = 0; c < C; ++c) {
+            const float wc = w[c];
+            if (VEC == 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(xp + (long long)c * HWv * 4);
+                a0 = __builtin_fmaf(wc, v.x, a0); a1 = __builtin_fmaf(wc, v.y, a1);
+                a2 = __builtin_fmaf(wc, v.z, a2); a3 = __builtin_fmaf(wc, v.w, a3);
+            } else {
+                a0 = __builtin_fmaf(wc, xp[(long long)c * HWv], a0);
+            }
+        }
+        if (VEC == 4) reinterpret_cast<float4 *>(out)[i] = make_float4(a0, a1, a2, a3);
+        else out[i] = a0;
+    }
+}
+
 static int grid_for(long long items)
 {
     long long blocks = (items + 255) / 256;
@@ -138,4 +192,33 @@ extern "C" int dmn_dpn_merge(const float *base, const float *yv, float *out, flo
     else     { if (act) DMN_MERGE(1, true); else DMN_MERGE(1, false); }
 #undef DMN_MERGE
     return launch_status("dmn_dpn_merge");
+}
+
+extern "C" int dmn_bn_relu_s2(const float *x, const float *mean, const float *scale, const float *bias,
+                              float *y, int N, int C, int H, int W, void *stream)
+{
+    if (!x || !mean || !scale || !bias || !y) return fail(-1, "dmn_bn_relu_s2: NULL pointer");
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || H % 2 || W % 4)
+        return fail(-4, "dmn_bn_relu_s2: needs H %% 2 == 0 and W %% 4 == 0 (N=%d C=%d H=%d W=%d)", N, C, H, W);
+    if (((uintptr_t)x & 15) || ((uintptr_t)y & 7)) return fail(-7, "dmn_bn_relu_s2: x must be 16-byte, y 8-byte aligned");
+    const long long total = (long long)N * C * (H / 2) * (W / 4);
+    hipLaunchKernelGGL(bn_relu_s2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       x, mean, scale, bias, y, total, C, H / 2, W / 4, W);
+    return launch_status("dmn_bn_relu_s2");
+}
+
+extern "C" int dmn_channel_dot(const float *x, const float *w, const float *bias0, float *out,
+                               int N, int C, int HW, void *stream)
+{
+    if (!x || !w || !out) return fail(-1, "dmn_channel_dot: NULL pointer");
+    if (N <= 0 || C <= 0 || HW <= 0) return fail(-4, "dmn_channel_dot: bad sizes N=%d C=%d HW=%d", N, C, HW);
+    hipStream_t s = (hipStream_t)stream;
+    if (HW % 4 == 0 && !(((uintptr_t)x | (uintptr_t)out) & 15)) {
+        const long long total = (long long)N * (HW / 4);
+        hipLaunchKernelGGL(channel_dot_kernel<4>, dim3(grid_for(total)), dim3(256), 0, s, x, w, bias0, out, total, C, HW / 4);
+    } else {
+        const long long total = (long long)N * HW;
+        hipLaunchKernelGGL(channel_dot_kernel<1>, dim3(grid_for(total)), dim3(256), 0, s, x, w, bias0, out, total, C, HW);
+    }
+    return launch_status("dmn_channel_dot");
 }

@@ -123,7 +123,8 @@ class BaseDMN(nn.Module):
             out, _ = self.mrnn(U0, tail=S, projected=True)
             out = out.permute(1, 2, 0).contiguous().view(B, -1, H, W)
             if not self.high_res:
-                out = self.output_collapse(out)
+                oc = self.output_collapse                              # dmn.py:213-214
+                out = ops.channel_dot(out, oc.weight.detach().view(-1), oc.bias.detach())
             return out
 
         # comb_conv split by input block [vis+coords | WE | h | P]  (dmn.py:114-118,187-192)
@@ -270,10 +271,39 @@ class UpsamplingModule(nn.Module):
                 else:
                     x = self.up(torch.cat([x, f], dim=1))
                 rest = list(level)[1:]
+            last = level is self.convs[-1]
+            if (last and not m and rest and rest[0] is conv and len(rest) == 1 and conv.bias is not None
+                    and self._can_reduce(x)):
+                # last level on MIOpen: its bias folds into out_layer's (both are linear), which
+                # saves the separate bias pass over the 512^2 x 32-channel tensor
+                x = F.conv2d(x, conv.weight, None, conv.stride, conv.padding)
+                return ops.channel_dot(x, self.out_layer.weight.view(-1), self._out_bias(conv))
             for layer in rest:
                 x = layer(x)
             i -= 1
+        if self._can_reduce(x):
+            return ops.channel_dot(x, self.out_layer.weight.view(-1), self._out_bias(None))
         return self.out_layer(x)
+
+    def _can_reduce(self, x):
+        return (not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32
+                and self.out_layer.out_channels == 1)
+
+    def _out_bias(self, conv):
+        """out_layer.bias (+ out_layer.weight . conv.bias when the preceding conv ran bias-free),
+        as a 1-element device tensor; cached per parameter version."""
+        ol = self.out_layer
+        ts = [ol.weight, ol.bias] + ([conv.bias] if conv is not None else [])
+        key = tuple((t._version, t.data_ptr()) for t in ts)
+        cached = self.__dict__.get("_dmn_out_bias")
+        if cached is None or cached[0] != key:
+            with torch.no_grad():
+                b = ol.bias.detach().clone().view(1)
+                if conv is not None:
+                    b = b + (ol.weight.detach().view(-1) * conv.bias.detach()).sum().view(1)
+            cached = (key, b.contiguous())
+            self.__dict__["_dmn_out_bias"] = cached
+        return cached[1]
 
 
 class DMN(nn.Module):

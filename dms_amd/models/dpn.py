@@ -162,7 +162,13 @@ class DualPathBlock(nn.Module):
             base = X
         else:
             w = self.c1x1_w_s2 if self.kind == "down" else self.c1x1_w_s1
-            base = _conv(w.conv, _bn_relu(w.bn, X))
+            if (self.kind == "down" and X.shape[2] % 2 == 0 and X.shape[3] % 4 == 0
+                    and w.conv.kernel_size == (1, 1) and w.conv.stride == (2, 2)):
+                # a stride-2 1x1 conv reads a quarter of its input: activate only that quarter,
+                # then it is the same batched GEMM as the stride-1 case
+                base = ops.conv1x1(ops.bn_relu_s2(X, *_bn_consts(w.bn)), w.conv.weight)
+            else:
+                base = _conv(w.conv, _bn_relu(w.bn, X))
         y = _conv(self.c1x1_a.conv, act_a)
         conv_b = self.c3x3_b.conv
         stride = conv_b.stride[0]

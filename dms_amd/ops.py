@@ -425,6 +425,30 @@ def bn_relu(x, mean, scale, bias):
     return y
 
 
+def bn_relu_s2(x, mean, scale, bias):
+    """relu(bn(x))[:, :, ::2, ::2] for x (N, C, H, W) with even H and W % 4 == 0."""
+    N, C, H, W = x.shape
+    _chk("bn_relu_s2", x)
+    _chk_bn("bn_relu_s2", (mean, scale, bias), C)
+    with torch.cuda.device(x.device):
+        y = torch.empty((N, C, H // 2, W // 2), device=x.device, dtype=torch.float32)
+        _lib.call("dmn_bn_relu_s2", _ptr(x), _ptr(mean), _ptr(scale), _ptr(bias), _ptr(y), N, C, H, W,
+                  _stream())
+    return y
+
+
+def channel_dot(x, w, bias0=None):
+    """(N, 1, H, W) = sum_c w[c] * x[:, c] + bias0: a 1x1 convolution to one channel.  Inference."""
+    N, C, H, W = x.shape
+    _chk("channel_dot", x)
+    _chk("channel_dot", w, (C,))
+    _chk("channel_dot", bias0, (1,) if bias0 is not None else None)
+    with torch.cuda.device(x.device):
+        out = torch.empty((N, 1, H, W), device=x.device, dtype=torch.float32)
+        _lib.call("dmn_channel_dot", _ptr(x), _ptr(w), _ptr(bias0), _ptr(out), N, C, H * W, _stream())
+    return out
+
+
 GCONV_GROUP_WIDTHS = (3, 4, 6, 8, 12, 16, 24, 32)
 
 

@@ -177,6 +177,14 @@ int dmn_wino_output_transform(const float *M, const float *bias, float *out,
                               int B, int Cout, int H, int W, int m, void *stream);
 
 /*
+ * 1x1 convolution to ONE output channel as a channel reduction: replaces
+ * `UpsamplingModule.out_layer` (dmn.py:327,341) and `output_collapse` (dmn.py:126-129,213-214):
+ *   out[n, p] = sum_c w[c] * x[n, c, p] + bias0[0]      x (N, C, HW), w (C), bias0 (1) or NULL
+ */
+int dmn_channel_dot(const float *x, const float *w, const float *bias0, float *out,
+                    int N, int C, int HW, void *stream);
+
+/*
  * Evaluation threshold sweep.  Replaces, per sample, the loop
  * `for thresh in score_thresh: compute_mask_IU((out > thresh).float(), mask)`
  * (dmn_pytorch/train.py:333-338 and 366-374) by one pass over the pixels.
@@ -217,6 +225,11 @@ int dmn_gconv3x3_bn_relu(const float *x, const float *w,
                          float *y, int N, int C, int H, int W, int groups, int stride, void *stream);
 int dmn_bn_relu(const float *x, const float *mean, const float *scale, const float *bias,
                 float *y, int N, int C, int HW, void *stream);
+/* dmn_bn_relu_s2: y (N, C, H/2, W/2) = relu(bn(x))[:, :, ::2, ::2] -- the pre-activation of the
+ * stride-2 1x1 projection `c1x1_w_s2` (dpn_model.py:208-213), which reads a quarter of x only.
+ * H % 2 == 0, W % 4 == 0. */
+int dmn_bn_relu_s2(const float *x, const float *mean, const float *scale, const float *bias,
+                   float *y, int N, int C, int H, int W, void *stream);
 int dmn_dpn_merge(const float *base, const float *yv, float *out, float *act,
                   const float *mean, const float *scale, const float *bias,
                   int N, int Cb, int Cy, int c1c, int HW, void *stream);

@@ -482,6 +482,27 @@ def test_bn_relu_matches_torch_eval_batchnorm(N, C, H, W):
     assert rel_err(got, want) < 1e-6
 
 
+@pytest.mark.parametrize("N,C,H,W", [(2, 5, 4, 4), (1, 3, 6, 12), (2, 64, 8, 8), (1, 1, 2, 4)])
+def test_bn_relu_stride2_matches_subsampled_torch(N, C, H, W):
+    x = det_uniform((N, C, H, W), 111, 2.0).to(DEV)
+    bn = (det_uniform((C,), 112, 1.0).to(DEV), det_uniform((C,), 113, 1.0).to(DEV).abs() + 0.5,
+          det_uniform((C,), 114, 0.5).to(DEV))
+    got = ops.bn_relu_s2(x, *bn)
+    assert torch.equal(got, ops.bn_relu(x, *bn)[:, :, ::2, ::2].contiguous())
+    with pytest.raises(RuntimeError, match="needs H"):
+        ops.bn_relu_s2(x[:, :, :, :W - 2].contiguous(), *bn)
+
+
+@pytest.mark.parametrize("N,C,H,W", [(2, 32, 8, 8), (1, 1005, 10, 10), (3, 7, 3, 5), (1, 1, 1, 1), (2, 32, 64, 64)])
+def test_channel_dot_matches_1x1_conv_to_one_channel(N, C, H, W):
+    x = det_uniform((N, C, H, W), 121, 1.0).to(DEV)
+    w = det_uniform((1, C, 1, 1), 122, 0.3).to(DEV)
+    b = det_uniform((1,), 123, 0.5).to(DEV)
+    want = F.conv2d(x.double(), w.double(), b.double()).float()
+    assert rel_err(ops.channel_dot(x, w.view(-1), b), want) < 1e-5
+    assert rel_err(ops.channel_dot(x, w.view(-1), None), want - b.view(1, 1, 1, 1)) < 1e-5
+
+
 @pytest.mark.parametrize("N,Cb,Cy,c1c,H,W", [(2, 7, 5, 3, 4, 4), (1, 6, 4, 4, 3, 5), (2, 336, 272, 256, 8, 8),
                                              (1, 4, 4, 4, 2, 2)])
 @pytest.mark.parametrize("with_bn", [False, True])
