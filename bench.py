@@ -116,6 +116,9 @@ class LaunchTimer(object):
         if name == "dmn_bn_relu_s2":
             N, C, H, W = args[5:9]
             return "dpn bn_relu stride 2", 4 * N * C * H * W * 3 // 4
+        if name == "dmn_head_final":
+            B, Cx, Cf, H, W = args[5:10]
+            return "head_final (cat+up+conv C->1) %dx%d" % (H, W), 4 * B * H * W * (Cx + Cf + 4)
         if name == "dmn_channel_dot":
             N, C, HW = args[4:7]
             return "channel_dot C=%d" % C, 4 * N * HW * (C + 1)

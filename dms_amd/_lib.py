@@ -33,6 +33,7 @@ SIGNATURES = {
     "dmn_cat_upsample2x_bwd": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
     "dmn_wino_cat_upsample2x_transform": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "dmn_wino_output_transform": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "dmn_head_final": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "dmn_threshold_iou": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
     "dmn_gconv3x3_bn_relu": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "dmn_bn_relu": [_p, _p, _p, _p, _p, _i, _i, _i, _p],

@@ -298,6 +298,104 @@ wino4_out_kernel(const float *__restrict__ M, const float *__restrict__ bias, fl
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Last head level + out_layer as ONE single-output-channel convolution.
+// UpsamplingModule ends with conv3x3(C -> Co) (dmn.py:324) followed directly by out_layer, a 1x1
+// conv Co -> 1 (dmn.py:327,341), with no non-linearity between them (non_linearity=False, the
+// reference default): their composition is a 3x3 conv C -> 1 with
+//     w_eff[c, tap] = sum_o w_out[o] * w[o, c, tap],  b_eff = b_out + sum_o w_out[o] * b[o],
+// i.e. Co (= 32) times fewer multiplies, and the (B, 32, 512, 512) tensor (1 GB at B = 32) is
+// never produced.  Fused with cat + bilinear x2 like the Winograd input transform: a lane owns
+// VEC low-res pixels = VEC 2x2 output tiles and walks the channels; for each channel it rebuilds
+// the 4x4 up-res patch of each tile from the 3x3 low-res neighbourhood.  HBM-bound on reading
+// x and feat once.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void up4(float lm, float l0, float lp, bool first, bool last, float o[4])
+{
+    o[0] = first ? 0.0f : __builtin_fmaf(0.75f, lm, 0.25f * l0);
+    o[1] = __builtin_fmaf(0.25f, lm, 0.75f * l0);
+    o[2] = __builtin_fmaf(0.75f, l0, 0.25f * lp);
+    o[3] = last ? 0.0f : __builtin_fmaf(0.25f, l0, 0.75f * lp);
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(256)
+head_final_kernel(const float *__restrict__ x, const float *__restrict__ feat,
+                  const float *__restrict__ weff, const float *__restrict__ bias0,
+                  float *__restrict__ out, int B, int Cx, int Cf, int H, int W)
+{
+    const int Wv = W / VEC;
+    const unsigned per_img = (unsigned)H * Wv;
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (unsigned)B * per_img) return;
+    const int b = idx / per_img;
+    const unsigned r = idx - b * per_img;
+    const int ty = r / Wv, tx0 = (r - ty * Wv) * VEC;
+    const int rows[3] = {(ty > 0 ? ty - 1 : 0) * W, ty * W, (ty < H - 1 ? ty + 1 : H - 1) * W};
+    const int cl = tx0 > 0 ? tx0 - 1 : 0, cr = tx0 + VEC < W ? tx0 + VEC : W - 1;
+    const bool top = ty == 0, bottom = ty == H - 1;
+    const float b0 = bias0 ? bias0[0] : 0.0f;
+    float y[VEC][2][2];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) y[e][0][0] = y[e][0][1] = y[e][1][0] = y[e][1][1] = b0;
+
+    const int C = Cx + Cf;
+    const size_t HW = (size_t)H * W;
+#pragma unroll 2
+    for (int c = 0; c < C; ++c) {
+        const float *plane = c < Cx ? x + ((size_t)b * Cx + c) * HW : feat + ((size_t)b * Cf + (c - Cx)) * HW;
+        const float *wc = weff + c * 9;                      // uniform: scalar loads
+        float g[3][VEC][4];                                  // column-upsampled low-res rows
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float *row = plane + rows[j];
+            float l[VEC + 2];
+            l[0] = row[cl];
+            if constexpr (VEC == 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(row + tx0);
+                l[1] = v.x; l[2] = v.y; l[3] = v.z; l[4] = v.w;
+            } else {
+                l[1] = row[tx0];
+            }
+            l[VEC + 1] = row[cr];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) up4(l[e], l[e + 1], l[e + 2], tx0 + e == 0, tx0 + e == W - 1, g[j][e]);
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            float d[4][4];                                   // up-res patch rows 2ty-1 .. 2ty+2
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float col[4];
+                up4(g[0][e][q], g[1][e][q], g[2][e][q], top, bottom, col);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) d[p][q] = col[p];
+            }
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const float wv = wc[dy * 3 + dx];
+                    y[e][0][0] = __builtin_fmaf(wv, d[dy][dx], y[e][0][0]);
+                    y[e][0][1] = __builtin_fmaf(wv, d[dy][dx + 1], y[e][0][1]);
+                    y[e][1][0] = __builtin_fmaf(wv, d[dy + 1][dx], y[e][1][0]);
+                    y[e][1][1] = __builtin_fmaf(wv, d[dy + 1][dx + 1], y[e][1][1]);
+                }
+        }
+    }
+    float *dst = out + ((size_t)b * 2 * H + 2 * ty) * 2 * W + 2 * tx0;
+    if constexpr (VEC == 4) {
+        float4 *d0 = reinterpret_cast<float4 *>(dst), *d1 = reinterpret_cast<float4 *>(dst + 2 * W);
+        d0[0] = make_float4(y[0][0][0], y[0][0][1], y[1][0][0], y[1][0][1]);
+        d0[1] = make_float4(y[2][0][0], y[2][0][1], y[3][0][0], y[3][0][1]);
+        d1[0] = make_float4(y[0][1][0], y[0][1][1], y[1][1][0], y[1][1][1]);
+        d1[1] = make_float4(y[2][1][0], y[2][1][1], y[3][1][0], y[3][1][1]);
+    } else {
+        dst[0] = y[0][0][0]; dst[1] = y[0][0][1];
+        dst[2 * W] = y[0][1][0]; dst[2 * W + 1] = y[0][1][1];
+    }
+}
+
 static int check_wino(const char *fn, int B, int C, int H, int W)
 {
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return fail(-4, "%s: bad sizes B=%d C=%d H=%d W=%d", fn, B, C, H, W);
@@ -358,4 +456,19 @@ extern "C" int dmn_wino_output_transform(const float *M, const float *bias, floa
     if (vec) hipLaunchKernelGGL(wino_out_kernel<4>, grid, dim3(256), 0, s, M, bias, out, B, Cout, H, W);
     else     hipLaunchKernelGGL(wino_out_kernel<1>, grid, dim3(256), 0, s, M, bias, out, B, Cout, H, W);
     return launch_status("dmn_wino_output_transform");
+}
+
+extern "C" int dmn_head_final(const float *x, const float *feat, const float *weff, const float *bias0,
+                              float *out, int B, int Cx, int Cf, int H, int W, void *stream)
+{
+    if (Cx < 0 || Cf < 0) return fail(-4, "dmn_head_final: negative channel count");
+    if (int rc = check_wino("dmn_head_final", B, Cx + Cf, H, W)) return rc;
+    if ((!x && Cx > 0) || (!feat && Cf > 0) || !weff || !out) return fail(-1, "dmn_head_final: NULL pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = W % 4 == 0 && !(((uintptr_t)x | (uintptr_t)feat | (uintptr_t)out) & 15);
+    const long long items = (long long)B * H * (vec ? W / 4 : W);
+    dim3 grid((unsigned)((items + 255) / 256));
+    if (vec) hipLaunchKernelGGL(head_final_kernel<4>, grid, dim3(256), 0, s, x, feat, weff, bias0, out, B, Cx, Cf, H, W);
+    else     hipLaunchKernelGGL(head_final_kernel<1>, grid, dim3(256), 0, s, x, feat, weff, bias0, out, B, Cx, Cf, H, W);
+    return launch_status("dmn_head_final");
 }

@@ -221,6 +221,7 @@ class UpsamplingModule(nn.Module):
         # batched rocBLAS GEMM.  "auto" = F(4x4) where measured faster than MIOpen, True / "f4" =
         # every eligible level, "f2" = F(2x2) (error ~7e-7 instead of ~1e-5 per level), False = never.
         self.winograd = "auto"
+        self.fuse_last = True      # inference: last level + out_layer as one C -> 1 conv (dmn_head_final)
 
     def _wino_weight(self, conv, m):
         """U = G g G^T of a level's conv weight, cached per weight version and tile size."""
@@ -258,6 +259,9 @@ class UpsamplingModule(nn.Module):
             if x.shape[-2:] != f.shape[-2:]:                      # dmn.py:332-336
                 x = F.interpolate(x, f.shape[-2:], mode='bilinear', align_corners=False)
             conv = level[1]
+            if level is self.convs[-1] and self._can_fuse_last(level, conv, x):
+                weff, b_eff = self._final_weights(conv)
+                return ops.head_final(x.contiguous(), f.contiguous(), weff, b_eff)
             m = self._winograd_tile(conv, x)
             if m:
                 B, _, H, W = x.shape
@@ -284,6 +288,32 @@ class UpsamplingModule(nn.Module):
         if self._can_reduce(x):
             return ops.channel_dot(x, self.out_layer.weight.view(-1), self._out_bias(None))
         return self.out_layer(x)
+
+    def _can_fuse_last(self, level, conv, x):
+        """Last level + out_layer as one single-output-channel 3x3 conv (no non-linearity between
+        them): inference, bilinear, plain 3x3 / pad 1 conv, out_layer to one channel."""
+        return (self.fuse_last and len(level) == 2 and self.mode == 'bilinear' and self._can_reduce(x)
+                and conv.kernel_size == (3, 3) and conv.padding == (1, 1) and conv.stride == (1, 1)
+                and conv.dilation == (1, 1) and conv.groups == 1
+                and self.out_layer.kernel_size == (1, 1))
+
+    def _final_weights(self, conv):
+        """w_eff (C, 3, 3) = sum_o w_out[o] * w[o], b_eff (1) = b_out + sum_o w_out[o] * b[o];
+        cached per parameter version."""
+        ol = self.out_layer
+        ts = [conv.weight, ol.weight, ol.bias] + ([conv.bias] if conv.bias is not None else [])
+        key = tuple((t._version, t.data_ptr()) for t in ts)
+        cached = self.__dict__.get("_dmn_final_w")
+        if cached is None or cached[0] != key:
+            with torch.no_grad():
+                wo = ol.weight.detach().view(-1).double()
+                weff = torch.einsum("o,ocyx->cyx", wo, conv.weight.detach().double())
+                b = ol.bias.detach().double().view(1)
+                if conv.bias is not None:
+                    b = b + (wo * conv.bias.detach().double()).sum().view(1)
+            cached = (key, (weff.float().contiguous(), b.float().contiguous()))
+            self.__dict__["_dmn_final_w"] = cached
+        return cached[1]
 
     def _can_reduce(self, x):
         return (not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32

@@ -404,6 +404,22 @@ def wino_output_transform(M, bias, B, H, W, m=2):
     return out
 
 
+def head_final(x, feat, weff, bias0=None):
+    """(B, 1, 2H, 2W) = conv3x3(upsample2x_bilinear(cat([x, feat], 1)), weff (C, 3, 3)) + bias0:
+    the last head level composed with out_layer (see dmn_head_final).  Inference only."""
+    B, Cx, H, W = x.shape
+    Cf = feat.shape[1]
+    _chk("head_final", x)
+    _chk("head_final", feat, (B, Cf, H, W))
+    _chk("head_final", weff, (Cx + Cf, 3, 3))
+    _chk("head_final", bias0, (1,) if bias0 is not None else None)
+    with torch.cuda.device(x.device):
+        out = torch.empty((B, 1, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
+        _lib.call("dmn_head_final", _ptr(x), _ptr(feat), _ptr(weff), _ptr(bias0), _ptr(out),
+                  B, Cx, Cf, H, W, _stream())
+    return out
+
+
 # ------------------------------------------------------------------------------------
 # DPN backbone glue (inference only: no autograd)
 # ------------------------------------------------------------------------------------

@@ -177,6 +177,17 @@ int dmn_wino_output_transform(const float *M, const float *bias, float *out,
                               int B, int Cout, int H, int W, int m, void *stream);
 
 /*
+ * Last head level and out_layer in one pass.  UpsamplingModule's last 3x3 conv (dmn.py:324) is
+ * followed directly by the 1x1 out_layer (dmn.py:327,341; no non-linearity between them by
+ * default), so their composition is a 3x3 conv to ONE channel; with cat + bilinear x2 fused in:
+ *   out (B, 1, 2H, 2W) = conv3x3_pad1( Upsample(x2)(cat([x, feat], 1)), weff ) + bias0[0]
+ *   x (B, Cx, H, W), feat (B, Cf, H, W); weff (Cx+Cf, 3, 3) = sum_o w_out[o] * w[o, :, :, :],
+ *   bias0 (1) = b_out + sum_o w_out[o] * b[o], both computed by the caller (tiny); bias0 may be NULL.
+ */
+int dmn_head_final(const float *x, const float *feat, const float *weff, const float *bias0,
+                   float *out, int B, int Cx, int Cf, int H, int W, void *stream);
+
+/*
  * 1x1 convolution to ONE output channel as a channel reduction: replaces
  * `UpsamplingModule.out_layer` (dmn.py:327,341) and `output_collapse` (dmn.py:126-129,213-214):
  *   out[n, p] = sum_c w[c] * x[n, c, p] + bias0[0]      x (N, C, HW), w (C), bias0 (1) or NULL

@@ -402,6 +402,24 @@ def test_winograd_level_matches_cat_upsample_conv(B, Cx, Cf, H, W, Cout, m):
     assert rel_err(got_nobias + bias.view(1, -1, 1, 1), want) < tol
 
 
+@pytest.mark.parametrize("B,Cx,Cf,H,W,Co", [(2, 3, 5, 4, 8, 6), (1, 2, 3, 3, 5, 4), (1, 4, 0, 1, 1, 3), (2, 8, 8, 16, 16, 32),
+                                            (1, 2, 2, 7, 12, 5)])
+def test_head_final_equals_conv_then_out_layer(B, Cx, Cf, H, W, Co):
+    """conv3x3(C -> Co) . out_layer(Co -> 1) composed into one C -> 1 conv on the upsampled cat."""
+    x = det_uniform((B, Cx, H, W), 131, 1.0).to(DEV)
+    f = det_uniform((B, Cf, H, W), 132, 1.0).to(DEV)
+    w = det_uniform((Co, Cx + Cf, 3, 3), 133, 0.3).to(DEV)
+    bias = det_uniform((Co,), 134, 0.5).to(DEV)
+    wo = det_uniform((1, Co, 1, 1), 135, 0.5).to(DEV)
+    bo = det_uniform((1,), 136, 0.5).to(DEV)
+    up = F.interpolate(torch.cat([x, f], 1), scale_factor=2, mode="bilinear", align_corners=False)
+    want = F.conv2d(F.conv2d(up.double(), w.double(), bias.double(), padding=1), wo.double(), bo.double()).float()
+    weff = torch.einsum("o,ocyx->cyx", wo.view(-1), w).contiguous()
+    beff = (bo + (wo.view(-1) * bias).sum()).view(1)
+    got = ops.head_final(x, f, weff, beff)
+    assert got.shape == want.shape and rel_err(got, want) < 1e-5
+
+
 def test_upsampling_module_winograd_path_matches_reference_golden():
     g = load_golden("upsample_small")
     fch = [6, 5, 4, 3, 2]
@@ -414,6 +432,9 @@ def test_upsampling_module_winograd_path_matches_reference_golden():
     with torch.no_grad():
         up.winograd = False
         y_plain = up(x, feats).cpu()
+        up.fuse_last = False
+        assert rel_err(up(x, feats).cpu(), y_plain) < 1e-5      # conv + out_layer unfused
+        up.fuse_last = True
         up.winograd = "f2"
         y = up(x, feats).cpu()
         assert rel_err(y, g["out"]) < 1e-4 and rel_err(y, y_plain) < 1e-5
