@@ -631,6 +631,34 @@ def test_dpn92_fused_glue_equals_plain_torch_backbone():
     assert out_g.requires_grad
 
 
+@pytest.mark.parametrize("high_res,size", [(True, (320, 320)), (False, (320, 320)), (True, (224, 352))])
+def test_dmn_every_inference_shortcut_equals_the_plain_path(high_res, size):
+    """BASELINE configs[0]/[3] image size (320 px: 10x10 .. 160x160 maps, widths that are not
+    multiples of 4 or 8) and a non-square one: the forward with every inference shortcut on
+    (DPN glue + grouped conv kernels, comb_conv fold, state-only scan, Winograd levels, fused
+    last level, channel reduction, per-shape BLAS) must equal the forward with all of them off
+    (torch modules + MIOpen + the unfused HIP path)."""
+    net = dms_amd.DMN(100, num_filters=10, lang_layers=3, mix_we=True, pretrained=False,
+                      high_res=high_res, upsampling_mode="bilinear", upsampling_amplification=32)
+    torch.nn.Module.load_state_dict(net, det_fill_state(net.state_dict()))
+    net = net.to(DEV).eval()
+    img = det_uniform((2, 3) + size, 141, 1.0).to(DEV)
+    words = det_ints((2, 7), 142, 100).to(DEV)
+    with torch.no_grad():
+        fast = net(img, words)
+        net.langvis.base.fuse_glue = False
+        net.langvis.fold_comb_into_msru = False
+        for cell in net.langvis.mrnn.rnn_lst:
+            cell.state_only_head = False
+        if high_res:
+            net.upsample.winograd = False
+            net.upsample.fuse_last = False
+        plain = net(img, words)
+    assert fast.shape == plain.shape == ((2, 1) + size if high_res else (2, 1, size[0] // 32, size[1] // 32))
+    assert rel_err(fast, plain) < 2e-5
+    assert ((fast > 0) == (plain > 0)).float().mean().item() >= 0.999
+
+
 def test_graphed_dmn_replay_equals_eager_forward():
     """One captured HIP graph per shape: replays must reproduce the eager forward bit for bit,
     for new inputs as well (static buffers), and reject other shapes."""
