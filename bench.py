@@ -119,6 +119,12 @@ class LaunchTimer(object):
         if name == "dmn_head_final":
             B, Cx, Cf, H, W = args[5:10]
             return "head_final (cat+up+conv C->1) %dx%d" % (H, W), 4 * B * H * W * (Cx + Cf + 4)
+        if name == "dmn_tap_upsample_gather":
+            B, Co, H, W = args[3:7]
+            return "tap_gather (9 planes -> up x2) %dx%d" % (H, W), 4 * B * Co * H * W * (9 + 4)
+        if name == "dmn_tap_project":
+            B, Cx, Cf, HW = args[4:8]
+            return "tap_project (C -> 9 rows)", 4 * B * HW * (Cx + Cf + 9)
         if name == "dmn_channel_dot":
             N, C, HW = args[4:7]
             return "channel_dot C=%d" % C, 4 * N * HW * (C + 1)

@@ -34,6 +34,8 @@ SIGNATURES = {
     "dmn_wino_cat_upsample2x_transform": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "dmn_wino_output_transform": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
     "dmn_head_final": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "dmn_tap_upsample_gather": [_p, _p, _p, _i, _i, _i, _i, _p],
+    "dmn_tap_project": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
     "dmn_threshold_iou": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
     "dmn_gconv3x3_bn_relu": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "dmn_bn_relu": [_p, _p, _p, _p, _p, _i, _i, _i, _p],

@@ -1,0 +1,215 @@
+// dms_amd/csrc/tapconv.hip -- high-res head level as "project at low res, gather at high res" (gfx950).
+//
+// One level of UpsamplingModule.forward (dmn_pytorch/models/dmn.py:324,337-338) computes
+//     y = conv3x3_pad1( Upsample(x2, bilinear)( cat([x, feat], 1) ) ) + bias.
+// Bilinear upsampling acts per channel and the channel mixing of a conv tap acts per pixel, so
+// the two commute:  W_tap . up(X) = up(W_tap . X).  The nine tap matrices are therefore applied
+// at LOW resolution by ONE plain library GEMM
+//     Z[b] (9*Cout, H*W) = Wt (9*Cout, Cx+Cf) . cat(x, feat)[b] (Cx+Cf, H*W)
+// (2.25 MACs per high-res output and input channel, the same as Winograd F(4x4,3x3), but exact
+// fp32 products, no input transform and no 2.25x-sized V tensor), and what is left is the
+// HBM-bound gather below: upsample each of the nine Z planes, shift it by its tap offset with
+// zero padding at the HIGH-res border, sum, add the bias.  cat() never happens: the GEMM is
+// split over K into an x part and a feat part by the caller.
+//
+// dmn_tap_project is the same projection for the case Cout == 1 (last level composed with
+// out_layer), where a 9-row GEMM would be a poor fit for the BLAS libraries: a lane owns 4
+// pixels and 9 accumulators each, the weights arrive as scalar operands.
+#include "common.h"
+
+namespace dmn {
+
+// One lane = CPL adjacent low-res columns of one (b, co) plane; it sweeps `RB` low-res rows and
+// keeps the horizontally finished rows r-1, r, r+1 of the three tap rows in registers.
+//   hrow[ky][c] = sum_kx upx(Z[ky*3+kx][r])[2*j0 + c + kx - 1]      c = 0 .. 2*CPL-1
+template <int CPL>
+struct TapRow {
+    float v[3][2 * CPL];
+};
+
+template <int CPL>
+__device__ __forceinline__ void tap_hrow(const float *__restrict__ zplane, long long tapstride,
+                                         int r, int W, int j0, TapRow<CPL> &R)
+{
+    const int jm = j0 > 0 ? j0 - 1 : 0;
+    const int jp = j0 + CPL < W ? j0 + CPL : W - 1;
+    const float ml = j0 > 0 ? 1.0f : 0.0f;              // high-res column 2*j0-1 exists
+    const float mr = j0 + CPL < W ? 1.0f : 0.0f;        // high-res column 2*(j0+CPL) exists
+    const long long rowoff = (long long)r * W;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+        for (int c = 0; c < 2 * CPL; ++c) R.v[ky][c] = 0.0f;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const float *z = zplane + (ky * 3 + kx) * tapstride + rowoff;
+            float zl[CPL + 2];
+            zl[0] = z[jm];
+            if (CPL == 2) {
+                const float2 m = *reinterpret_cast<const float2 *>(z + j0);
+                zl[1] = m.x; zl[2] = m.y;
+            } else {
+                zl[1] = z[j0];
+            }
+            zl[CPL + 1] = z[jp];
+            // u[q] = upx(z)[2*j0 - 1 + q], q = 0 .. 2*CPL+1
+            float u[2 * CPL + 2];
+            u[0] = ml * (0.75f * zl[0] + 0.25f * zl[1]);
+#pragma unroll
+            for (int m = 0; m < CPL; ++m) {
+                u[1 + 2 * m] = 0.25f * zl[m] + 0.75f * zl[m + 1];
+                u[2 + 2 * m] = 0.75f * zl[m + 1] + 0.25f * zl[m + 2];
+            }
+            u[2 * CPL + 1] = mr * (0.25f * zl[CPL] + 0.75f * zl[CPL + 1]);
+#pragma unroll
+            for (int c = 0; c < 2 * CPL; ++c) R.v[ky][c] += u[c + kx];
+        }
+    }
+}
+
+template <int CPL>
+__global__ void __launch_bounds__(256)
+tap_gather_kernel(const float *__restrict__ Z, const float *__restrict__ bias, float *__restrict__ out,
+                  int B, int Cout, int H, int W, int RB)
+{
+    const int Wl = (W + CPL - 1) / CPL;
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)B * Cout * Wl;
+    if (g >= total) return;
+    const int plane = (int)(g / Wl), jl = (int)(g - (long long)plane * Wl);
+    const int b = plane / Cout, co = plane - b * Cout;
+    const int j0 = jl * CPL;
+    const int r0 = blockIdx.y * RB;
+    const int r1 = r0 + RB < H ? r0 + RB : H;
+    const long long HW = (long long)H * W;
+    const long long tapstride = (long long)Cout * HW;
+    const float *zplane = Z + ((long long)b * 9 * Cout + co) * HW;
+    const float bv = bias ? bias[co] : 0.0f;
+    float *oplane = out + (long long)plane * 4 * HW;
+    const int W2 = 2 * W;
+
+    TapRow<CPL> Rm, Rc, Rp;
+    tap_hrow<CPL>(zplane, tapstride, r0 > 0 ? r0 - 1 : 0, W, j0, Rm);
+    tap_hrow<CPL>(zplane, tapstride, r0, W, j0, Rc);
+    for (int i = r0; i < r1; ++i) {
+        tap_hrow<CPL>(zplane, tapstride, i + 1 < H ? i + 1 : H - 1, W, j0, Rp);
+        const float mt = i > 0 ? 1.0f : 0.0f;          // high-res row 2i-1 exists
+        const float mb = i + 1 < H ? 1.0f : 0.0f;      // high-res row 2i+2 exists
+        float o0[2 * CPL], o1[2 * CPL];
+#pragma unroll
+        for (int c = 0; c < 2 * CPL; ++c) {
+            o0[c] = bv + mt * (0.75f * Rm.v[0][c] + 0.25f * Rc.v[0][c])
+                       + (0.25f * Rm.v[1][c] + 0.75f * Rc.v[1][c])
+                       + (0.75f * Rc.v[2][c] + 0.25f * Rp.v[2][c]);
+            o1[c] = bv + (0.25f * Rm.v[0][c] + 0.75f * Rc.v[0][c])
+                       + (0.75f * Rc.v[1][c] + 0.25f * Rp.v[1][c])
+                       + mb * (0.25f * Rc.v[2][c] + 0.75f * Rp.v[2][c]);
+        }
+        float *p0 = oplane + (long long)(2 * i) * W2 + 2 * j0;
+        float *p1 = p0 + W2;
+        if (CPL == 2) {
+            *reinterpret_cast<float4 *>(p0) = make_float4(o0[0], o0[1], o0[2 * CPL - 2], o0[2 * CPL - 1]);
+            *reinterpret_cast<float4 *>(p1) = make_float4(o1[0], o1[1], o1[2 * CPL - 2], o1[2 * CPL - 1]);
+        } else {
+            *reinterpret_cast<float2 *>(p0) = make_float2(o0[0], o0[1]);
+            *reinterpret_cast<float2 *>(p1) = make_float2(o1[0], o1[1]);
+        }
+        Rm = Rc;
+        Rc = Rp;
+    }
+}
+
+// Z[b, r, p] = sum_c w[r, c] * in[b, c, p], r = 0..8, in = cat(x, feat) over channels (never built).
+// VEC pixels per lane; the weight reads are uniform (scalar loads).
+template <int VEC>
+__global__ void __launch_bounds__(256)
+tap_project_kernel(const float *__restrict__ x, const float *__restrict__ feat,
+                   const float *__restrict__ w, float *__restrict__ Z, int Cx, int Cf, int HW)
+{
+    const int b = blockIdx.y;
+    const int p = (blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+    if (p >= HW) return;
+    const int C = Cx + Cf;
+    float acc[9][VEC];
+#pragma unroll
+    for (int r = 0; r < 9; ++r)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[r][e] = 0.0f;
+    for (int half = 0; half < 2; ++half) {
+        const int n = half ? Cf : Cx, c0 = half ? Cx : 0;
+        const float *src = (half ? feat : x) + (long long)b * n * HW + p;
+#pragma unroll 4
+        for (int c = 0; c < n; ++c) {
+            float v[VEC];
+            if (VEC == 4) {
+                const float4 t = *reinterpret_cast<const float4 *>(src + (long long)c * HW);
+                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[VEC - 1] = t.w;
+            } else {
+                v[0] = src[(long long)c * HW];
+            }
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                const float wv = w[r * C + c0 + c];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[r][e] = __builtin_fmaf(wv, v[e], acc[r][e]);
+            }
+        }
+    }
+    float *zp = Z + (long long)b * 9 * HW + p;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        if (VEC == 4) *reinterpret_cast<float4 *>(zp + (long long)r * HW) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][VEC - 1]);
+        else zp[(long long)r * HW] = acc[r][0];
+    }
+}
+
+}  // namespace dmn
+
+using namespace dmn;
+
+extern "C" int dmn_tap_upsample_gather(const float *Z, const float *bias, float *out,
+                                       int B, int Cout, int H, int W, void *stream)
+{
+    if (!Z || !out) return fail(-1, "dmn_tap_upsample_gather: NULL pointer");
+    if (B <= 0 || Cout <= 0 || H <= 0 || W <= 0)
+        return fail(-4, "dmn_tap_upsample_gather: bad sizes B=%d Cout=%d H=%d W=%d", B, Cout, H, W);
+    if ((long long)B * Cout >= (1LL << 31) / 4)
+        return fail(-5, "dmn_tap_upsample_gather: B*Cout=%lld too large", (long long)B * Cout);
+    const bool two = (W % 2 == 0) && !(((uintptr_t)Z & 7) | ((uintptr_t)out & 15));
+    if (!two && ((uintptr_t)out & 7))
+        return fail(-5, "dmn_tap_upsample_gather: out must be 8-byte aligned");
+    const int Wl = two ? W / 2 : W;
+    const long long total = (long long)B * Cout * Wl;
+    const long long blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffLL) return fail(-5, "dmn_tap_upsample_gather: grid too large");
+    // rows per lane: as long as possible (2 halo rows are recomputed per chunk) while the launch
+    // still has ~8 wavefronts per SIMD
+    int RB = H;
+    while (RB > 8 && blocks * 4 * ((H + RB - 1) / RB) < 8192) RB = (RB + 1) / 2;
+    const int chunks = (H + RB - 1) / RB;
+    if (chunks > 65535) return fail(-5, "dmn_tap_upsample_gather: H=%d too large", H);
+    dim3 grid((unsigned)blocks, chunks);
+    hipStream_t s = (hipStream_t)stream;
+    if (two) hipLaunchKernelGGL(tap_gather_kernel<2>, grid, dim3(256), 0, s, Z, bias, out, B, Cout, H, W, RB);
+    else hipLaunchKernelGGL(tap_gather_kernel<1>, grid, dim3(256), 0, s, Z, bias, out, B, Cout, H, W, RB);
+    return launch_status("dmn_tap_upsample_gather");
+}
+
+extern "C" int dmn_tap_project(const float *x, const float *feat, const float *w, float *Z,
+                               int B, int Cx, int Cf, int HW, void *stream)
+{
+    if (!w || !Z || (Cx > 0 && !x) || (Cf > 0 && !feat)) return fail(-1, "dmn_tap_project: NULL pointer");
+    if (B <= 0 || Cx < 0 || Cf < 0 || Cx + Cf <= 0 || HW <= 0)
+        return fail(-4, "dmn_tap_project: bad sizes B=%d Cx=%d Cf=%d HW=%d", B, Cx, Cf, HW);
+    if (B > 65535) return fail(-5, "dmn_tap_project: B=%d exceeds the grid y limit", B);
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = (HW % 4 == 0) && !(((uintptr_t)x | (uintptr_t)feat | (uintptr_t)Z) & 15);
+    if (vec) {
+        dim3 grid((HW / 4 + 255) / 256, B);
+        hipLaunchKernelGGL(tap_project_kernel<4>, grid, dim3(256), 0, s, x, feat, w, Z, Cx, Cf, HW);
+    } else {
+        dim3 grid((HW + 255) / 256, B);
+        hipLaunchKernelGGL(tap_project_kernel<1>, grid, dim3(256), 0, s, x, feat, w, Z, Cx, Cf, HW);
+    }
+    return launch_status("dmn_tap_project");
+}

@@ -221,7 +221,32 @@ class UpsamplingModule(nn.Module):
         # batched rocBLAS GEMM.  "auto" = F(4x4) where measured faster than MIOpen, True / "f4" =
         # every eligible level, "f2" = F(2x2) (error ~7e-7 instead of ~1e-5 per level), False = never.
         self.winograd = "auto"
-        self.fuse_last = True      # inference: last level + out_layer as one C -> 1 conv (dmn_head_final)
+        self.fuse_last = True      # inference: last level + out_layer as one C -> 1 conv
+        # inference: a level's 3x3 conv applied as nine tap matrices at LOW resolution (one plain
+        # library GEMM; upsampling and channel mixing commute) followed by one gather pass at
+        # high resolution (ops.tap_gemm / tap_upsample_gather).  Same multiply count as F(4x4)
+        # Winograd, exact fp32 products, no transformed-input tensor.  Takes precedence over
+        # `winograd`; False falls back to it.
+        self.tap_gemm = True
+
+    def _tap_ok(self, conv, x):
+        return (self.tap_gemm and self.mode == 'bilinear' and not torch.is_grad_enabled()
+                and x.is_cuda and x.dtype == torch.float32
+                and conv.kernel_size == (3, 3) and conv.padding == (1, 1) and conv.stride == (1, 1)
+                and conv.dilation == (1, 1) and conv.groups == 1)
+
+    def _tap_weights(self, conv, cx):
+        """(Wt[:, :cx], Wt[:, cx:]) of a level's conv weight in tap-major row order, cached per
+        weight version."""
+        w = conv.weight
+        key = (w._version, w.data_ptr(), cx)
+        cached = conv.__dict__.get("_dmn_tap")
+        if cached is None or cached[0] != key:
+            with torch.no_grad():
+                wt = ops.tap_weight(w.detach())
+                cached = (key, (wt[:, :cx].contiguous(), wt[:, cx:].contiguous()))
+            conv.__dict__["_dmn_tap"] = cached
+        return cached[1]
 
     def _wino_weight(self, conv, m):
         """U = G g G^T of a level's conv weight, cached per weight version and tile size."""
@@ -260,10 +285,17 @@ class UpsamplingModule(nn.Module):
                 x = F.interpolate(x, f.shape[-2:], mode='bilinear', align_corners=False)
             conv = level[1]
             if level is self.convs[-1] and self._can_fuse_last(level, conv, x):
-                weff, b_eff = self._final_weights(conv)
+                weff, b_eff, w9 = self._final_weights(conv)
+                if self._tap_ok(conv, x):
+                    return ops.tap_upsample_gather(ops.tap_project(x.contiguous(), f.contiguous(), w9), b_eff)
                 return ops.head_final(x.contiguous(), f.contiguous(), weff, b_eff)
-            m = self._winograd_tile(conv, x)
-            if m:
+            m = 0 if self._tap_ok(conv, x) else self._winograd_tile(conv, x)
+            if self._tap_ok(conv, x):
+                wt_x, wt_f = self._tap_weights(conv, x.shape[1])
+                Z = ops.tap_gemm(x.contiguous(), f.contiguous(), wt_x, wt_f)
+                x = ops.tap_upsample_gather(Z, conv.bias)
+                rest = list(level)[2:]
+            elif m:
                 B, _, H, W = x.shape
                 V = ops.wino_cat_upsample2x_transform(x.contiguous(), f.contiguous(), m)
                 M = ops.tuned_matmul(self._wino_weight(conv, m), V)
@@ -276,7 +308,7 @@ class UpsamplingModule(nn.Module):
                     x = self.up(torch.cat([x, f], dim=1))
                 rest = list(level)[1:]
             last = level is self.convs[-1]
-            if (last and not m and rest and rest[0] is conv and len(rest) == 1 and conv.bias is not None
+            if (last and rest and rest[0] is conv and len(rest) == 1 and conv.bias is not None
                     and self._can_reduce(x)):
                 # last level on MIOpen: its bias folds into out_layer's (both are linear), which
                 # saves the separate bias pass over the 512^2 x 32-channel tensor
@@ -298,8 +330,8 @@ class UpsamplingModule(nn.Module):
                 and self.out_layer.kernel_size == (1, 1))
 
     def _final_weights(self, conv):
-        """w_eff (C, 3, 3) = sum_o w_out[o] * w[o], b_eff (1) = b_out + sum_o w_out[o] * b[o];
-        cached per parameter version."""
+        """w_eff (C, 3, 3) = sum_o w_out[o] * w[o], b_eff (1) = b_out + sum_o w_out[o] * b[o] and
+        w_eff again as (9, C) tap rows; cached per parameter version."""
         ol = self.out_layer
         ts = [conv.weight, ol.weight, ol.bias] + ([conv.bias] if conv.bias is not None else [])
         key = tuple((t._version, t.data_ptr()) for t in ts)
@@ -311,7 +343,8 @@ class UpsamplingModule(nn.Module):
                 b = ol.bias.detach().double().view(1)
                 if conv.bias is not None:
                     b = b + (wo * conv.bias.detach().double()).sum().view(1)
-            cached = (key, (weff.float().contiguous(), b.float().contiguous()))
+            weff = weff.float().contiguous()
+            cached = (key, (weff, b.float().contiguous(), weff.view(weff.shape[0], 9).t().contiguous()))
             self.__dict__["_dmn_final_w"] = cached
         return cached[1]
 

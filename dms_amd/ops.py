@@ -77,8 +77,9 @@ def _time_matmul(name, a, b, reps=3):
     return e0.elapsed_time(e1)
 
 
-def tuned_matmul(a, b):
-    """torch.matmul(a, b) with the BLAS library (rocBLAS / hipBLASLt) chosen PER SHAPE: neither
+def tuned_matmul(a, b, acc=None):
+    """torch.matmul(a, b) (+ acc, accumulated in place, when given: a (M, K), b (B, K, N),
+    acc (B, M, N)) with the BLAS library (rocBLAS / hipBLASLt) chosen PER SHAPE: neither
     wins everywhere on MI355X (profiles/r1_conv1x1_backend_probe.txt: hipBLASLt is 10-25 % faster
     on DPN92's conv2_x / conv4_x 1x1 shapes, rocBLAS on the others and on the mSRU projections).
     The choice is timed once per shape on first use (a few launches and one event wait; not
@@ -99,7 +100,10 @@ def tuned_matmul(a, b):
                 choice = min(t, key=t.get)
                 _BMM_CHOICE[key] = choice
         torch.backends.cuda.preferred_blas_library(choice)
-        out = torch.matmul(a, b)
+        if acc is None:
+            out = torch.matmul(a, b)
+        else:
+            out = torch.baddbmm(acc, a.unsqueeze(0).expand(b.shape[0], -1, -1), b, out=acc)
     finally:
         torch.backends.cuda.preferred_blas_library(prev)
     return out
@@ -418,6 +422,59 @@ def head_final(x, feat, weff, bias0=None):
         _lib.call("dmn_head_final", _ptr(x), _ptr(feat), _ptr(weff), _ptr(bias0), _ptr(out),
                   B, Cx, Cf, H, W, _stream())
     return out
+
+
+# ------------------------------------------------------------------------------------
+# Head level as "tap GEMM at low resolution + gather at high resolution" (inference only)
+# ------------------------------------------------------------------------------------
+def tap_weight(weight):
+    """Wt (9*Cout, C) with row (ky*3+kx)*Cout + o = w[o, :, ky, kx] of a (Cout, C, 3, 3) weight."""
+    Cout, C = weight.shape[:2]
+    return weight.permute(2, 3, 0, 1).reshape(9 * Cout, C).contiguous()
+
+
+def tap_gemm(x, feat, wt_x, wt_f):
+    """Z (B, 9, Cout, H, W) = Wt . cat([x, feat], 1) per sample, as one library GEMM per source
+    (the second accumulates into the first's output, so the concat is never built)."""
+    B, Cx, H, W = x.shape
+    Cf = feat.shape[1]
+    R = wt_x.shape[0]
+    _chk("tap_gemm", x)
+    _chk("tap_gemm", feat, (B, Cf, H, W))
+    _chk("tap_gemm", wt_x, (R, Cx))
+    _chk("tap_gemm", wt_f, (R, Cf))
+    Z = None
+    if Cx:
+        Z = tuned_matmul(wt_x, x.view(B, Cx, H * W))
+    if Cf:
+        Z = tuned_matmul(wt_f, feat.view(B, Cf, H * W), acc=Z)
+    return Z.view(B, 9, R // 9, H, W)
+
+
+def tap_upsample_gather(Z, bias):
+    """out (B, Cout, 2H, 2W) = bias + sum over the 9 taps of shift_tap(upsample2x(Z[:, tap]))
+    (zero outside the high-res image); Z (B, 9, Cout, H, W)."""
+    B, nine, Cout, H, W = Z.shape
+    _chk("tap_upsample_gather", Z, (B, 9, Cout, H, W))
+    _chk("tap_upsample_gather", bias, (Cout,) if bias is not None else None)
+    with torch.cuda.device(Z.device):
+        out = torch.empty((B, Cout, 2 * H, 2 * W), device=Z.device, dtype=torch.float32)
+        _lib.call("dmn_tap_upsample_gather", _ptr(Z), _ptr(bias), _ptr(out), B, Cout, H, W, _stream())
+    return out
+
+
+def tap_project(x, feat, w9):
+    """Z (B, 9, 1, H, W) = w9 (9, Cx+Cf) . cat([x, feat], 1): the tap projection to ONE channel."""
+    B, Cx, H, W = x.shape
+    Cf = feat.shape[1]
+    _chk("tap_project", x)
+    _chk("tap_project", feat, (B, Cf, H, W))
+    _chk("tap_project", w9, (9, Cx + Cf))
+    with torch.cuda.device(x.device):
+        Z = torch.empty((B, 9, 1, H, W), device=x.device, dtype=torch.float32)
+        _lib.call("dmn_tap_project", _ptr(x) if Cx else None, _ptr(feat) if Cf else None, _ptr(w9),
+                  _ptr(Z), B, Cx, Cf, H * W, _stream())
+    return Z
 
 
 # ------------------------------------------------------------------------------------

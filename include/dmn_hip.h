@@ -188,6 +188,28 @@ int dmn_head_final(const float *x, const float *feat, const float *weff, const f
                    float *out, int B, int Cx, int Cf, int H, int W, void *stream);
 
 /*
+ * High-res head level at inference as "project at low resolution, gather at high resolution".
+ * Replaces, for one level of UpsamplingModule.forward (dmn.py:324,337-338),
+ *   conv3x3_pad1(Upsample(x2, bilinear)(cat([x, feat], 1))) + bias.
+ * Bilinear upsampling (per channel) and a conv tap's channel mixing (per pixel) commute, so the
+ * caller applies the nine tap matrices at LOW resolution with a plain library GEMM,
+ *   Z[b] (9*Cout, H*W) = Wt (9*Cout, Cx+Cf) . cat(x, feat)[b],  Wt[(ky*3+kx)*Cout + o, c] = w[o, c, ky, kx]
+ * (split over K into an x and a feat GEMM, so cat() is never built; 2.25 MACs per output and
+ * input channel like Winograd F(4x4), but exact fp32 products), and
+ * dmn_tap_upsample_gather does the rest in one HBM-bound pass:
+ *   out[b, o, y, x] = bias[o] + sum_{ky,kx} up2(Z[b, ky*3+kx, o])[y + ky - 1, x + kx - 1]
+ *   with up2 = bilinear x2 (align_corners=False) and zero outside the (2H, 2W) image.
+ *   Z (B, 9, Cout, H, W) -> out (B, Cout, 2H, 2W); bias (Cout) or NULL.
+ * dmn_tap_project: the projection itself for the 9-row case Cout == 1 (last level composed with
+ * out_layer, see dmn_head_final), where a GEMM with 9 rows is a poor fit for a BLAS library:
+ *   Z (B, 9, HW) = w (9, Cx+Cf) . cat(x, feat)[b];  x (B, Cx, HW), feat (B, Cf, HW) (either may be empty).
+ */
+int dmn_tap_upsample_gather(const float *Z, const float *bias, float *out,
+                            int B, int Cout, int H, int W, void *stream);
+int dmn_tap_project(const float *x, const float *feat, const float *w, float *Z,
+                    int B, int Cx, int Cf, int HW, void *stream);
+
+/*
  * 1x1 convolution to ONE output channel as a channel reduction: replaces
  * `UpsamplingModule.out_layer` (dmn.py:327,341) and `output_collapse` (dmn.py:126-129,213-214):
  *   out[n, p] = sum_c w[c] * x[n, c, p] + bias0[0]      x (N, C, HW), w (C), bias0 (1) or NULL

@@ -420,6 +420,53 @@ def test_head_final_equals_conv_then_out_layer(B, Cx, Cf, H, W, Co):
     assert got.shape == want.shape and rel_err(got, want) < 1e-5
 
 
+@pytest.mark.parametrize("B,Cx,Cf,H,W,Cout", [(2, 3, 5, 4, 8, 6), (1, 2, 3, 3, 5, 4), (1, 4, 0, 2, 4, 3),
+                                              (2, 16, 16, 16, 16, 32), (1, 3, 2, 1, 1, 2), (1, 2, 2, 1, 4, 2),
+                                              (3, 5, 4, 7, 12, 9), (1, 3, 3, 2, 2, 2), (2, 4, 3, 6, 10, 5),
+                                              (1, 8, 8, 8, 24, 4), (1, 0, 3, 5, 3, 2), (2, 3, 3, 40, 20, 3),
+                                              (1, 2, 1, 33, 130, 2)])
+def test_tap_gemm_level_matches_cat_upsample_conv(B, Cx, Cf, H, W, Cout):
+    """nine tap matrices at low resolution (library GEMM) + gather at high resolution ==
+    conv3x3(upsample2x(cat)) (dmn.py:324,337-338), incl. odd sizes, 1-pixel maps, empty sources."""
+    x = det_uniform((B, Cx, H, W), 91, 1.0).to(DEV)
+    f = det_uniform((B, Cf, H, W), 92, 1.0).to(DEV)
+    w = det_uniform((Cout, Cx + Cf, 3, 3), 93, 0.3).to(DEV)
+    bias = det_uniform((Cout,), 94, 0.5).to(DEV)
+    up = F.interpolate(torch.cat([x, f], 1), scale_factor=2, mode="bilinear", align_corners=False)
+    want = F.conv2d(up.double(), w.double(), bias.double(), padding=1).float()
+    wt = ops.tap_weight(w)
+    assert wt.shape == (9 * Cout, Cx + Cf) and torch.equal(wt[4 * Cout:5 * Cout], w[:, :, 1, 1])
+    Z = ops.tap_gemm(x, f, wt[:, :Cx].contiguous(), wt[:, Cx:].contiguous())
+    assert Z.shape == (B, 9, Cout, H, W)
+    got = ops.tap_upsample_gather(Z, bias)
+    assert got.shape == want.shape and rel_err(got, want) < 2e-6
+    got_nobias = ops.tap_upsample_gather(Z, None)
+    assert rel_err(got_nobias + bias.view(1, -1, 1, 1), want) < 2e-6
+
+
+@pytest.mark.parametrize("B,Cx,Cf,H,W,Co", [(2, 3, 5, 4, 8, 6), (1, 2, 3, 3, 5, 4), (1, 4, 0, 1, 1, 3), (2, 8, 8, 16, 16, 32),
+                                            (1, 2, 2, 7, 12, 5), (1, 0, 6, 9, 7, 2), (2, 64, 64, 32, 64, 32)])
+def test_tap_project_and_gather_equal_conv_then_out_layer(B, Cx, Cf, H, W, Co):
+    """last level composed with out_layer: 9-row projection kernel + gather == conv3x3 . out_layer."""
+    x = det_uniform((B, Cx, H, W), 131, 1.0).to(DEV)
+    f = det_uniform((B, Cf, H, W), 132, 1.0).to(DEV)
+    w = det_uniform((Co, Cx + Cf, 3, 3), 133, 0.3).to(DEV)
+    bias = det_uniform((Co,), 134, 0.5).to(DEV)
+    wo = det_uniform((1, Co, 1, 1), 135, 0.5).to(DEV)
+    bo = det_uniform((1,), 136, 0.5).to(DEV)
+    up = F.interpolate(torch.cat([x, f], 1), scale_factor=2, mode="bilinear", align_corners=False)
+    want = F.conv2d(F.conv2d(up.double(), w.double(), bias.double(), padding=1), wo.double(), bo.double()).float()
+    weff = torch.einsum("o,ocyx->cyx", wo.view(-1), w).contiguous()
+    beff = (bo + (wo.view(-1) * bias).sum()).view(1)
+    w9 = weff.view(Cx + Cf, 9).t().contiguous()
+    Z = ops.tap_project(x, f, w9)
+    assert Z.shape == (B, 9, 1, H, W)
+    zref = torch.einsum("rc,bchw->brhw", w9.double(), torch.cat([x, f], 1).double()).float()
+    assert rel_err(Z.view(B, 9, H, W), zref) < 2e-6
+    got = ops.tap_upsample_gather(Z, beff)
+    assert got.shape == want.shape and rel_err(got, want) < 5e-6
+
+
 def test_upsampling_module_winograd_path_matches_reference_golden():
     g = load_golden("upsample_small")
     fch = [6, 5, 4, 3, 2]
@@ -430,8 +477,11 @@ def test_upsampling_module_winograd_path_matches_reference_golden():
     feats = [None, None, det_uniform((1, fch[2], 12, 16), 306, 1.0).to(DEV),
              det_uniform((1, fch[1], 6, 8), 305, 1.0).to(DEV), det_uniform((1, fch[0], 3, 4), 304, 1.0).to(DEV)]
     with torch.no_grad():
+        y_tap = up(x, feats).cpu()                            # default: tap GEMM + gather levels
+        up.tap_gemm = False
         up.winograd = False
         y_plain = up(x, feats).cpu()
+        assert rel_err(y_tap, g["out"]) < 1e-4 and rel_err(y_tap, y_plain) < 1e-5
         up.fuse_last = False
         assert rel_err(up(x, feats).cpu(), y_plain) < 1e-5      # conv + out_layer unfused
         up.fuse_last = True
@@ -458,6 +508,7 @@ def test_whole_dmn_winograd_head_matches_reference_end_to_end():
                       high_res=True, upsampling_mode="bilinear", upsampling_amplification=32)
     torch.nn.Module.load_state_dict(net, det_fill_state(net.state_dict()))
     net = net.to(DEV).eval()
+    net.upsample.tap_gemm = False
     net.upsample.winograd = True
     img = det_uniform((1, 3, 64, 64), 404, 1.0).to(DEV)
     words = det_ints((1, 6), 405, 100).to(DEV)
@@ -636,7 +687,7 @@ def test_dmn_every_inference_shortcut_equals_the_plain_path(high_res, size):
     """BASELINE configs[0]/[3] image size (320 px: 10x10 .. 160x160 maps, widths that are not
     multiples of 4 or 8) and a non-square one: the forward with every inference shortcut on
     (DPN glue + grouped conv kernels, comb_conv fold, state-only scan, Winograd levels, fused
-    last level, channel reduction, per-shape BLAS) must equal the forward with all of them off
+    last level, tap-GEMM head levels, channel reduction, per-shape BLAS) must equal the forward with all of them off
     (torch modules + MIOpen + the unfused HIP path)."""
     net = dms_amd.DMN(100, num_filters=10, lang_layers=3, mix_we=True, pretrained=False,
                       high_res=high_res, upsampling_mode="bilinear", upsampling_amplification=32)
@@ -651,6 +702,7 @@ def test_dmn_every_inference_shortcut_equals_the_plain_path(high_res, size):
         for cell in net.langvis.mrnn.rnn_lst:
             cell.state_only_head = False
         if high_res:
+            net.upsample.tap_gemm = False
             net.upsample.winograd = False
             net.upsample.fuse_last = False
         plain = net(img, words)
@@ -693,6 +745,9 @@ def test_head_full_size_winograd_equals_miopen_path_and_shards_by_batch():
     feats = [torch.randn((2, c, s, s), device=DEV, generator=gen)
              for c, s in ((64, 256), (336, 128), (704, 64), (1552, 32), (2688, 16))]
     with torch.no_grad():
+        tap = up(x, feats)                                    # default: tap GEMM + gather levels
+        tap_one = up(x[1:], [f[1:] for f in feats])
+        up.tap_gemm = False
         up.winograd = False
         ref = up(x, feats)
         up.winograd = "auto"
@@ -700,9 +755,10 @@ def test_head_full_size_winograd_equals_miopen_path_and_shards_by_batch():
         one = up(x[1:], [f[1:] for f in feats])
         up.winograd = "f2"
         got2 = up(x, feats)
-    assert got.shape == (2, 1, 512, 512)
+    assert got.shape == tap.shape == (2, 1, 512, 512)
     assert rel_err(got, ref) < 5e-5 and rel_err(got2, ref) < 1e-5
     assert rel_err(one, got[1:]) < 1e-5
+    assert rel_err(tap, ref) < 1e-5 and rel_err(tap_one, tap[1:]) < 1e-5
 
 
 def test_sru_full_size_chunked_equals_whole_and_column_subset_oracle():

@@ -1,4 +1,4 @@
-"""High-res head alone at B=32: UpsamplingModule with winograd = False / "f2" / "auto" / True."""
+"""High-res head alone at B=32: UpsamplingModule with tap_gemm, then winograd = False / "f2" / "auto" / True."""
 import os
 import sys
 
@@ -27,8 +27,14 @@ def timeit(fn, n=5):
 
 
 with torch.no_grad():
+    up.tap_gemm = False
     up.winograd = False
     ref = up(x, feats)
+    up.tap_gemm = True
+    y = up(x, feats)
+    err = ((y - ref).abs().max() / ref.abs().max()).item()
+    print("tap_gemm        %.2f ms   rel diff vs MIOpen path %.2e" % (timeit(lambda: up(x, feats)), err), flush=True)
+    up.tap_gemm = False
     for mode in (False, "f2", "auto", True):
         up.winograd = mode
         y = up(x, feats)
