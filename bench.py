@@ -128,6 +128,9 @@ class LaunchTimer(object):
         if name == "dmn_channel_dot":
             N, C, HW = args[4:7]
             return "channel_dot C=%d" % C, 4 * N * HW * (C + 1)
+        if name == "dmn_bn_relu_maxpool":
+            N, C, H, W = args[5:9]
+            return "stem bn_relu+maxpool", 4 * N * C * H * W * 5 // 4
         if name == "dmn_bn_relu":
             N, C, HW = args[5:8]
             return "dpn bn_relu (all shapes)", 8 * N * C * HW
@@ -349,6 +352,8 @@ def main():
     ap.add_argument("--workload", default="dmn512", choices=["dmn512", "msru_stress", "train320"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=5)
+    ap.add_argument("--no-gemm-table", action="store_true",
+                    help="do not load the recorded per-shape BLAS solution table (dms_amd/tuning/)")
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 64 if args.workload == "train320" else 32
@@ -403,6 +408,8 @@ def main():
             print(json.dumps(line))
         return
 
+    from dms_amd import ops as dmn_ops
+    gemm_table_entries = 0 if args.no_gemm_table else dmn_ops.use_gemm_table()
     net = build_model(device)
     B = args.batch
     g = torch.Generator(device=device).manual_seed(SEED + rank)
@@ -452,6 +459,7 @@ def main():
                        "parallelism": "batch-sharded replicas, no collective"},
             "roofline": roofline,
             "msru_GBs": dom["achieved_GBs"],
+            "gemm_table_entries": gemm_table_entries,
             "hip_kernels_ms_per_step": round(hip_ms, 3),
             "hip_kernels": kernels}
 

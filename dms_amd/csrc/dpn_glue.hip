@@ -112,6 +112,51 @@ bn_relu_s2_kernel(const float *__restrict__ x, const float *__restrict__ mean,
     }
 }
 
+// y = maxpool3x3/stride2/pad1( relu(bn(x)) ): the stem's bn + act + pool (dpn_model.py:186-197) in
+// one pass over the raw conv output (which has to stay in memory as pyramid level 0).  After the
+// ReLU every value is >= 0, so the pool's implicit -inf padding can be 0.  One lane = 2 adjacent
+// output columns (one aligned float4 of input + its left neighbour) x RO output rows; the
+// horizontal maxima of the row shared by two consecutive windows are carried in registers.
+__global__ void __launch_bounds__(256)
+bn_relu_maxpool_kernel(const float *__restrict__ x, const float *__restrict__ mean,
+                       const float *__restrict__ scale, const float *__restrict__ bias,
+                       float *__restrict__ y, long long total, int C, int H, int W, int Ho, int RO)
+{
+    const int Wq = W / 4, Wo = W / 2;
+    const int nchunk = (Ho + RO - 1) / RO;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int l = (int)(i % Wq);
+        const long long t = i / Wq;
+        const int oy0 = (int)(t % nchunk) * RO;
+        const long long pl = t / nchunk;                           // n * C + c
+        const int c = (int)(pl % C);
+        const float m = mean[c], s = scale[c], b = bias[c];
+        const float *xp = x + pl * H * W + 4 * l;
+        auto hrow = [&](int r, float &h0, float &h1) {
+            const float4 v = *reinterpret_cast<const float4 *>(xp + (long long)r * W);
+            const float left = l > 0 ? fmaxf(__builtin_fmaf(xp[(long long)r * W - 1] - m, s, b), 0.0f) : 0.0f;
+            const float a0 = fmaxf(__builtin_fmaf(v.x - m, s, b), 0.0f);
+            const float a1 = fmaxf(__builtin_fmaf(v.y - m, s, b), 0.0f);
+            const float a2 = fmaxf(__builtin_fmaf(v.z - m, s, b), 0.0f);
+            const float a3 = fmaxf(__builtin_fmaf(v.w - m, s, b), 0.0f);
+            h0 = fmaxf(fmaxf(left, a0), a1);
+            h1 = fmaxf(fmaxf(a1, a2), a3);
+        };
+        float p0 = 0.0f, p1 = 0.0f;
+        if (oy0 > 0) hrow(2 * oy0 - 1, p0, p1);
+        const int oy1 = oy0 + RO < Ho ? oy0 + RO : Ho;
+        for (int oy = oy0; oy < oy1; ++oy) {
+            float c0, c1, n0 = 0.0f, n1 = 0.0f;
+            hrow(2 * oy, c0, c1);
+            if (2 * oy + 1 < H) hrow(2 * oy + 1, n0, n1);
+            *reinterpret_cast<float2 *>(y + (pl * Ho + oy) * Wo + 2 * l) =
+                make_float2(fmaxf(fmaxf(p0, c0), n0), fmaxf(fmaxf(p1, c1), n1));
+            p0 = n0; p1 = n1;
+        }
+    }
+}
+
 // out[n,p] = sum_c w[c] * x[n,c,p] + bias0: a 1x1 convolution to ONE channel (the head's out_layer,
 // dmn.py:327,341, and output_collapse, dmn.py:213) is a channel reduction that reads x once.
 template <int VEC>
@@ -205,6 +250,20 @@ extern "C" int dmn_bn_relu_s2(const float *x, const float *mean, const float *sc
     hipLaunchKernelGGL(bn_relu_s2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                        x, mean, scale, bias, y, total, C, H / 2, W / 4, W);
     return launch_status("dmn_bn_relu_s2");
+}
+
+extern "C" int dmn_bn_relu_maxpool(const float *x, const float *mean, const float *scale, const float *bias,
+                                   float *y, int N, int C, int H, int W, void *stream)
+{
+    if (!x || !mean || !scale || !bias || !y) return fail(-1, "dmn_bn_relu_maxpool: NULL pointer");
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || W % 4)
+        return fail(-4, "dmn_bn_relu_maxpool: needs W %% 4 == 0 (N=%d C=%d H=%d W=%d)", N, C, H, W);
+    if (((uintptr_t)x & 15) || ((uintptr_t)y & 7)) return fail(-7, "dmn_bn_relu_maxpool: x must be 16-byte, y 8-byte aligned");
+    const int Ho = (H - 1) / 2 + 1, RO = 4;
+    const long long total = (long long)N * C * ((Ho + RO - 1) / RO) * (W / 4);
+    hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       x, mean, scale, bias, y, total, C, H, W, Ho, RO);
+    return launch_status("dmn_bn_relu_maxpool");
 }
 
 extern "C" int dmn_channel_dot(const float *x, const float *w, const float *bias0, float *out,

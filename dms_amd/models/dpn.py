@@ -215,7 +215,12 @@ class DPN(nn.Module):
         stem = children[0][1]
         blocks, final = children[1:-1], children[-1][1]
         raw = stem.conv(x)
-        X = stem.pool(_bn_relu(stem.bn, raw))
+        pool = stem.pool
+        if (raw.shape[3] % 4 == 0 and pool.kernel_size == 3 and pool.stride == 2 and pool.padding == 1
+                and pool.dilation == 1 and not pool.ceil_mode):
+            X = ops.bn_relu_maxpool(raw, *_bn_consts(stem.bn))    # bn + relu + pool: one pass
+        else:
+            X = pool(_bn_relu(stem.bn, raw))
         feats = [raw]
         act = None
         for i, (name, block) in enumerate(blocks):

@@ -62,6 +62,31 @@ def gemm_backend():
         torch.backends.cuda.preferred_blas_library(prev)
 
 
+GEMM_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning", "gemm_mi355x_b32_512px.csv")
+
+
+def use_gemm_table(path=None):
+    """Opt in to a recorded per-shape solution table for the library GEMMs (PyTorch TunableOp in
+    look-up mode: no tuning at run time).  The table shipped in dms_amd/tuning/ was searched on
+    one MI355X over all rocBLAS + hipBLASLt fp32 solutions for every GEMM shape of the B=32 /
+    512 px inference step (tools/tune_gemms.py); shapes it does not hold keep the library's own
+    choice.  TunableOp ignores the file unless its validator lines (torch, HIP, rocBLAS,
+    hipBLASLt versions, gfx arch) match the running stack.  Process-global.  Returns the number
+    of entries loaded (0: file missing or rejected)."""
+    import torch.cuda.tunable as tunable
+    path = path or os.environ.get("DMN_GEMM_TABLE", GEMM_TABLE)
+    if path in ("0", "off") or not os.path.exists(path):
+        return 0
+    tunable.enable(True)
+    tunable.tuning_enable(False)
+    tunable.set_filename(path)
+    ok = tunable.read_file(path)
+    n = len(tunable.get_results()) if ok else 0
+    if not n:
+        tunable.enable(False)
+    return n
+
+
 _BMM_CHOICE = {}
 
 
@@ -506,6 +531,18 @@ def bn_relu_s2(x, mean, scale, bias):
     with torch.cuda.device(x.device):
         y = torch.empty((N, C, H // 2, W // 2), device=x.device, dtype=torch.float32)
         _lib.call("dmn_bn_relu_s2", _ptr(x), _ptr(mean), _ptr(scale), _ptr(bias), _ptr(y), N, C, H, W,
+                  _stream())
+    return y
+
+
+def bn_relu_maxpool(x, mean, scale, bias):
+    """MaxPool2d(3, 2, 1)(relu(bn(x))) for x (N, C, H, W) with W % 4 == 0: the stem's bn + act + pool."""
+    N, C, H, W = x.shape
+    _chk("bn_relu_maxpool", x)
+    _chk_bn("bn_relu_maxpool", (mean, scale, bias), C)
+    with torch.cuda.device(x.device):
+        y = torch.empty((N, C, (H - 1) // 2 + 1, W // 2), device=x.device, dtype=torch.float32)
+        _lib.call("dmn_bn_relu_maxpool", _ptr(x), _ptr(mean), _ptr(scale), _ptr(bias), _ptr(y), N, C, H, W,
                   _stream())
     return y
 

@@ -263,6 +263,11 @@ int dmn_bn_relu(const float *x, const float *mean, const float *scale, const flo
  * H % 2 == 0, W % 4 == 0. */
 int dmn_bn_relu_s2(const float *x, const float *mean, const float *scale, const float *bias,
                    float *y, int N, int C, int H, int W, void *stream);
+/* dmn_bn_relu_maxpool: y (N, C, (H-1)/2+1, W/2) = MaxPool2d(3, stride 2, padding 1)(relu(bn(x))) -- the
+ * stem's bn + act + pool (InputBlock, dpn_model.py:186-197) in one pass over the raw conv output
+ * (which stays in memory as pyramid level 0).  W % 4 == 0. */
+int dmn_bn_relu_maxpool(const float *x, const float *mean, const float *scale, const float *bias,
+                        float *y, int N, int C, int H, int W, void *stream);
 int dmn_dpn_merge(const float *base, const float *yv, float *out, float *act,
                   const float *mean, const float *scale, const float *bias,
                   int N, int Cb, int Cy, int c1c, int HW, void *stream);

@@ -554,6 +554,18 @@ def test_bn_relu_matches_torch_eval_batchnorm(N, C, H, W):
     assert rel_err(got, want) < 1e-6
 
 
+@pytest.mark.parametrize("N,C,H,W", [(2, 5, 4, 4), (1, 3, 7, 12), (2, 64, 32, 32), (1, 1, 1, 4), (1, 2, 9, 8), (2, 3, 160, 160)])
+def test_bn_relu_maxpool_matches_torch_stem(N, C, H, W):
+    """stem bn + relu + MaxPool2d(3, 2, 1) (dpn_model.py:186-197) in one pass; bit-exact pooling."""
+    x = det_uniform((N, C, H, W), 181, 2.0).to(DEV)
+    mean = det_uniform((C,), 182, 0.5).to(DEV)
+    scale = det_uniform((C,), 183, 1.5).to(DEV)               # negative scales too
+    bias = det_uniform((C,), 184, 0.5).to(DEV)
+    want = F.max_pool2d(ops.bn_relu(x, mean, scale, bias), 3, 2, 1)
+    got = ops.bn_relu_maxpool(x, mean, scale, bias)
+    assert got.shape == want.shape and torch.equal(got, want)
+
+
 @pytest.mark.parametrize("N,C,H,W", [(2, 5, 4, 4), (1, 3, 6, 12), (2, 64, 8, 8), (1, 1, 2, 4)])
 def test_bn_relu_stride2_matches_subsampled_torch(N, C, H, W):
     x = det_uniform((N, C, H, W), 111, 2.0).to(DEV)
