@@ -42,6 +42,7 @@ __device__ __forceinline__ float tanh_f(float v)
 
 // streaming (write-once) 16-byte store: non-temporal, does not displace L2 / MALL lines
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void store_stream4(float *p, float a, float b, float c, float d)
 {
     f32x4_t v = {a, b, c, d};

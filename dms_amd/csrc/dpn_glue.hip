@@ -72,7 +72,7 @@ dpn_merge_kernel(const float *__restrict__ base, const float *__restrict__ yv,
             } else {
                 o = reinterpret_cast<const float4 *>(yv)[iy];
             }
-            reinterpret_cast<float4 *>(out)[i] = o;
+            reinterpret_cast<float4 *>(out)[i] = o;          // (non-temporal: measured, no difference)
             if (BN) {
                 float4 r;
                 r.x = fmaxf(__builtin_fmaf(o.x - m, s, b), 0.0f);

@@ -131,6 +131,8 @@ gconv3x3_kernel(const float *__restrict__ x, const float *__restrict__ w,
 // Register budget: the kernel is HBM/latency-bound, so occupancy matters more than keeping every
 // weight and prefetched row in registers (unconstrained, hipcc used 188 VGPRs for CG = 3, i.e.
 // 2 waves per SIMD, and the kernel ran at 20 % of HBM bandwidth).
+// (Measured and rejected: capping the CG = 12 instantiation at 128 VGPRs so that the 4 workgroups
+// per CU of DPN92's conv4 stage run in one round -- the 37 spilled dwords cost more, 59 vs 56 us.)
 template <int CG, int SPLIT>
 __global__ void __launch_bounds__(256)
 gconv3x3_rows_kernel(const float *__restrict__ x, const float *__restrict__ w,
@@ -171,11 +173,19 @@ gconv3x3_rows_kernel(const float *__restrict__ x, const float *__restrict__ w,
         row_off[r] = (gy < 0 ? 0 : (gy < H ? gy : H - 1)) * W;
     }
 
-    float acc[COS][GC_PX];
+    // even widths: two adjacent output channels per v_pk_fma_f32 (weight pair = one 64-bit scalar
+    // operand, the pixel broadcast through op_sel): twice the fp32 FMA rate of v_fma_f32
+    constexpr bool PK = (CG % 2 == 0) && (COS % 2 == 0);
+    float acc[PK ? 1 : COS][GC_PX];
+    f32x2_t accp[PK ? COS / 2 : 1][GC_PX];
 #pragma unroll
-    for (int co = 0; co < COS; ++co)
+    for (int co = 0; co < (PK ? 1 : COS); ++co)
 #pragma unroll
         for (int p = 0; p < GC_PX; ++p) acc[co][p] = 0.0f;
+#pragma unroll
+    for (int co = 0; co < (PK ? COS / 2 : 1); ++co)
+#pragma unroll
+        for (int p = 0; p < GC_PX; ++p) accp[co][p] = (f32x2_t){0.0f, 0.0f};
 
     const float *xin = x + ((size_t)n * C + c0) * H * W;
     // software pipeline over the input channels: the raw rows of channel ci + 1 are requested
@@ -219,12 +229,22 @@ gconv3x3_rows_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                          tx == txn - 1 ? rr : from_r};
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
+                if constexpr (PK) {
 #pragma unroll
-                for (int co = 0; co < COS; ++co) {
-                    const float wv = wp[(r * 3 + dx) * CG + co];
+                    for (int cp = 0; cp < COS / 2; ++cp) {
+                        const f32x2_t wv = *reinterpret_cast<const f32x2_t *>(wp + (r * 3 + dx) * CG + 2 * cp);
 #pragma unroll
-                    for (int p = 0; p < GC_PX; ++p)
-                        acc[co][p] = __builtin_fmaf(wv, in[p + dx], acc[co][p]);
+                        for (int p = 0; p < GC_PX; ++p)
+                            accp[cp][p] = __builtin_elementwise_fma(wv, (f32x2_t){in[p + dx], in[p + dx]}, accp[cp][p]);
+                    }
+                } else {
+#pragma unroll
+                    for (int co = 0; co < COS; ++co) {
+                        const float wv = wp[(r * 3 + dx) * CG + co];
+#pragma unroll
+                        for (int p = 0; p < GC_PX; ++p)
+                            acc[co][p] = __builtin_fmaf(wv, in[p + dx], acc[co][p]);
+                    }
                 }
             }
         }
@@ -246,7 +266,7 @@ gconv3x3_rows_kernel(const float *__restrict__ x, const float *__restrict__ w,
     for (int co = 0; co < COS; ++co) {
         float o[GC_PX];
 #pragma unroll
-        for (int p = 0; p < GC_PX; ++p) o[p] = acc[co][p];
+        for (int p = 0; p < GC_PX; ++p) o[p] = PK ? accp[PK ? co / 2 : 0][p][co % 2] : acc[PK ? 0 : co][p];
         if (m2) {
             const int c = c0 + part * COS + co;
             const float mm = m2[c], ss = s2[c], bb = b2[c];
@@ -295,11 +315,19 @@ gconv3x3_s2_kernel(const float *__restrict__ x, const float *__restrict__ w,
         row_off[r] = (gy < 0 ? 0 : (gy < H ? gy : H - 1)) * W;
     }
 
-    float acc[COS][GC_PX];
+    // even widths: two adjacent output channels per v_pk_fma_f32 (weight pair = one 64-bit scalar
+    // operand, the pixel broadcast through op_sel): twice the fp32 FMA rate of v_fma_f32
+    constexpr bool PK = (CG % 2 == 0) && (COS % 2 == 0);
+    float acc[PK ? 1 : COS][GC_PX];
+    f32x2_t accp[PK ? COS / 2 : 1][GC_PX];
 #pragma unroll
-    for (int co = 0; co < COS; ++co)
+    for (int co = 0; co < (PK ? 1 : COS); ++co)
 #pragma unroll
         for (int p = 0; p < GC_PX; ++p) acc[co][p] = 0.0f;
+#pragma unroll
+    for (int co = 0; co < (PK ? COS / 2 : 1); ++co)
+#pragma unroll
+        for (int p = 0; p < GC_PX; ++p) accp[co][p] = (f32x2_t){0.0f, 0.0f};
 
     const float *xin = x + ((size_t)n * C + c0) * H * W;
     struct Raw { float4 a[3], b[3]; float l[3]; };
@@ -333,12 +361,22 @@ gconv3x3_s2_kernel(const float *__restrict__ x, const float *__restrict__ w,
             const float in[9] = {tx == 0 ? l : from_l, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
+                if constexpr (PK) {
 #pragma unroll
-                for (int co = 0; co < COS; ++co) {
-                    const float wv = wp[(r * 3 + dx) * CG + co];
+                    for (int cp = 0; cp < COS / 2; ++cp) {
+                        const f32x2_t wv = *reinterpret_cast<const f32x2_t *>(wp + (r * 3 + dx) * CG + 2 * cp);
 #pragma unroll
-                    for (int p = 0; p < GC_PX; ++p)
-                        acc[co][p] = __builtin_fmaf(wv, in[2 * p + dx], acc[co][p]);
+                        for (int p = 0; p < GC_PX; ++p)
+                            accp[cp][p] = __builtin_elementwise_fma(wv, (f32x2_t){in[2 * p + dx], in[2 * p + dx]}, accp[cp][p]);
+                    }
+                } else {
+#pragma unroll
+                    for (int co = 0; co < COS; ++co) {
+                        const float wv = wp[(r * 3 + dx) * CG + co];
+#pragma unroll
+                        for (int p = 0; p < GC_PX; ++p)
+                            acc[co][p] = __builtin_fmaf(wv, in[2 * p + dx], acc[co][p]);
+                    }
                 }
             }
         }
@@ -360,7 +398,7 @@ gconv3x3_s2_kernel(const float *__restrict__ x, const float *__restrict__ w,
     for (int co = 0; co < COS; ++co) {
         float o[GC_PX];
 #pragma unroll
-        for (int p = 0; p < GC_PX; ++p) o[p] = acc[co][p];
+        for (int p = 0; p < GC_PX; ++p) o[p] = PK ? accp[PK ? co / 2 : 0][p][co % 2] : acc[PK ? 0 : co][p];
         if (m2) {
             const int c = c0 + part * COS + co;
             const float mm = m2[c], ss = s2[c], bb = b2[c];
@@ -388,7 +426,8 @@ extern "C" int dmn_gconv3x3_bn_relu(const float *x, const float *w,
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || groups <= 0 || C % groups)
         return fail(-4, "dmn_gconv3x3_bn_relu: bad sizes N=%d C=%d H=%d W=%d groups=%d", N, C, H, W, groups);
     if (N > 65535 || groups > 65535) return fail(-5, "dmn_gconv3x3_bn_relu: N or groups exceed the grid limits");
-    if (((uintptr_t)x | (uintptr_t)y) & 15) return fail(-7, "dmn_gconv3x3_bn_relu: x and y must be 16-byte aligned");
+    if ((((uintptr_t)x | (uintptr_t)y) & 15) || ((uintptr_t)w & 7))
+        return fail(-7, "dmn_gconv3x3_bn_relu: x and y must be 16-byte, w 8-byte aligned");
     const int cg = C / groups;
     if (stride == 2) {
         if (H % 2 || W % 8) return fail(-4, "dmn_gconv3x3_bn_relu: stride 2 needs H %% 2 == 0 and W %% 8 == 0 (got %dx%d)", H, W);

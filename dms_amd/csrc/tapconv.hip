@@ -16,7 +16,6 @@
 // out_layer), where a 9-row GEMM would be a poor fit for the BLAS libraries: a lane owns 4
 // pixels and 9 accumulators each, the weights arrive as scalar operands.
 #include "common.h"
-#include <cstdlib>
 
 namespace dmn {
 
@@ -186,8 +185,7 @@ extern "C" int dmn_tap_upsample_gather(const float *Z, const float *bias, float 
     // rows per lane: as long as possible (2 halo rows are recomputed per chunk) while the launch
     // still has ~8 wavefronts per SIMD
     int RB = H;
-    static const int target = getenv("DMN_TAP_WAVES") ? atoi(getenv("DMN_TAP_WAVES")) : 8192;   // tuning knob
-    while (RB > 8 && blocks * 4 * ((H + RB - 1) / RB) < target) RB = (RB + 1) / 2;
+    while (RB > 16 && blocks * 4 * ((H + RB - 1) / RB) < 8192) RB = (RB + 1) / 2;   // (2048 .. 32768: no difference)
     const int chunks = (H + RB - 1) / RB;
     if (chunks > 65535) return fail(-5, "dmn_tap_upsample_gather: H=%d too large", H);
     dim3 grid((unsigned)blocks, chunks);

@@ -51,7 +51,6 @@ with torch.no_grad():
     net(img, words)
     torch.cuda.synchronize()
 print("tuning pass: %.1f s, %d entries" % (time.perf_counter() - t0, len(tunable.get_results())), flush=True)
-tunable.write_file(out)
 tunable.tuning_enable(False)
 tuned_ms, y1 = timeit()
 err = ((y1 - y0).abs().max() / y0.abs().max()).item()
