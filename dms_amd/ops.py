@@ -7,6 +7,7 @@ anything else raises (there is no CPU or eager fallback).
 """
 import contextlib
 import os
+import tempfile
 
 import torch
 
@@ -79,8 +80,10 @@ def use_gemm_table(path=None):
         return 0
     tunable.enable(True)
     tunable.tuning_enable(False)
-    tunable.set_filename(path)
     ok = tunable.read_file(path)
+    # TunableOp writes its results back to "its" file; keep that away from the shipped table
+    # (several ranks share it) by pointing it at a per-process scratch name
+    tunable.set_filename(os.path.join(tempfile.gettempdir(), "dmn_tunableop_unused_%d.csv" % os.getpid()))
     n = len(tunable.get_results()) if ok else 0
     if not n:
         tunable.enable(False)

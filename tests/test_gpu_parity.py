@@ -6,6 +6,7 @@ Tolerances: fp32, logits within 1e-4 relative (BASELINE.json north_star); kernel
 v_exp_f32 / v_rcp_f32 (1 ulp) so element-wise checks use rtol 1e-4 + atol 1e-5 at most
 and in practice sit near 1e-6.
 """
+import os
 import numpy as np
 import pytest
 import torch
@@ -798,3 +799,29 @@ def test_sru_full_size_chunked_equals_whole_and_column_subset_oracle():
     # time-parallel variant agrees at full length as well
     h3, _, c3 = ops.sru_forward_raw(u, x, bias, None, "tanh", 1.0, nchunks=16)
     assert rel_err(h3, h) < 1e-5 and rel_err(c3, cl) < 1e-5
+
+
+def test_recorded_gemm_table_lookup_keeps_results_and_leaves_the_table_alone():
+    """ops.use_gemm_table(): TunableOp in look-up mode with the shipped per-shape solution table.
+    A shape the table holds (DPN92 conv4 c1x1_a at B=32) must still match an fp64 reference,
+    no tuning may happen at run time, and the shipped file must not be rewritten."""
+    import hashlib
+    import torch.cuda.tunable as tunable
+    with open(ops.GEMM_TABLE, "rb") as f:
+        before = hashlib.md5(f.read()).hexdigest()
+    n = ops.use_gemm_table()
+    try:
+        assert n > 0, "table rejected: validators do not match this torch/ROCm stack"
+        assert tunable.is_enabled() and not tunable.tuning_is_enabled()
+        assert os.path.abspath(tunable.get_filename()) != os.path.abspath(ops.GEMM_TABLE)
+        gen = torch.Generator(device=DEV).manual_seed(5)
+        x = torch.randn((32, 1312, 32, 32), device=DEV, generator=gen)
+        w = torch.randn((384, 1312, 1, 1), device=DEV, generator=gen) * 0.05
+        got = ops.conv1x1(x, w)
+        want = torch.matmul(w.view(384, 1312).double(), x[:2].view(2, 1312, 1024).double()).float()
+        assert rel_err(got[:2].reshape(2, 384, 1024), want) < 1e-5
+        assert len(tunable.get_results()) == n                # nothing was tuned on the fly
+    finally:
+        tunable.enable(False)
+    with open(ops.GEMM_TABLE, "rb") as f:
+        assert hashlib.md5(f.read()).hexdigest() == before
