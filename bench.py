@@ -134,6 +134,10 @@ class LaunchTimer(object):
         if name == "dmn_bn_relu":
             N, C, HW = args[5:8]
             return "dpn bn_relu (all shapes)", 8 * N * C * HW
+        if name == "dmn_dpn_stage_pass":
+            N, rows, c1c, inc, Co, HW = args[6:12]
+            return ("dpn stage pass (in-place merge + bn_relu, all shapes)",
+                    4 * N * HW * (2 * Co + 2 * inc + (Co if args[2] else 0)))
         if name == "dmn_dpn_merge":
             N, Cb, Cy, c1c, HW = args[7:12]
             Co = Cb + Cy - c1c

@@ -42,6 +42,7 @@ SIGNATURES = {
     "dmn_bn_relu_s2": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "dmn_bn_relu_maxpool": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "dmn_channel_dot": [_p, _p, _p, _p, _i, _i, _i, _p],
+    "dmn_dpn_stage_pass": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "dmn_dpn_merge": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
 }
 

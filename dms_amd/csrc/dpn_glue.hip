@@ -89,6 +89,58 @@ dpn_merge_kernel(const float *__restrict__ base, const float *__restrict__ yv,
     }
 }
 
+// In-place variant of the merge for a whole DPN stage.  The stage keeps ONE buffer per sample,
+//   rows: [ dense0 (2*inc) | res (c1c) | slot (inc) | o2_1 (inc) | o2_2 (inc) | ... ]
+// The block's last 1x1 convolution is a library GEMM with beta = 1 whose output rows are
+// [res | slot]: the residual add `resid = x_s1 + out1` (dpn_model.py:265-266) happens in the GEMM's
+// epilogue and the new dense channels `out2` land in the (zeroed) slot.  This pass then produces
+// the next consumer's pre-activation in the REFERENCE channel order
+//   [ res | dense0 | o2_1 .. o2_k | slot ]         (cat(resid, cat(x_s2, out2)), dpn_model.py:246,267-269)
+// moves the slot's channels to their final rows, clears the slot for the next block and, on request
+// (pyramid taps), writes the block output itself in reference order.  Compared with dmn_dpn_merge
+// the residual and old dense channels are read once and never copied.
+template <int VEC>
+__global__ void __launch_bounds__(256)
+dpn_stage_pass_kernel(float *__restrict__ buf, float *__restrict__ act, float *__restrict__ out,
+                      const float *__restrict__ mean, const float *__restrict__ scale,
+                      const float *__restrict__ bias, long long total, int rows, int c1c, int inc,
+                      int Co, int HWv)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int hw = (int)(i % HWv);
+        const long long pl = i / HWv;
+        const int c = (int)(pl % Co);
+        const long long n = pl / Co;
+        const bool fresh = c >= Co - inc;                               // this block's out2: in the slot
+        const int row = c < c1c ? 2 * inc + c : (c < c1c + 2 * inc ? c - c1c : (fresh ? c1c + 2 * inc + c - (Co - inc) : c + inc));
+        const long long src = ((n * rows + row) * HWv + hw);
+        const float m = mean[c], s = scale[c], b = bias[c];
+        if (VEC == 4) {
+            const float4 v = reinterpret_cast<const float4 *>(buf)[src];
+            if (fresh) {
+                reinterpret_cast<float4 *>(buf)[(n * rows + c + inc) * HWv + hw] = v;
+                reinterpret_cast<float4 *>(buf)[src] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+            float4 r;
+            r.x = fmaxf(__builtin_fmaf(v.x - m, s, b), 0.0f);
+            r.y = fmaxf(__builtin_fmaf(v.y - m, s, b), 0.0f);
+            r.z = fmaxf(__builtin_fmaf(v.z - m, s, b), 0.0f);
+            r.w = fmaxf(__builtin_fmaf(v.w - m, s, b), 0.0f);
+            reinterpret_cast<float4 *>(act)[i] = r;
+            if (out) reinterpret_cast<float4 *>(out)[i] = v;
+        } else {
+            const float v = buf[src];
+            if (fresh) {
+                buf[(n * rows + c + inc) * HWv + hw] = v;
+                buf[src] = 0.0f;
+            }
+            act[i] = fmaxf(__builtin_fmaf(v - m, s, b), 0.0f);
+            if (out) out[i] = v;
+        }
+    }
+}
+
 // y[n,c,oy,ox] = relu(bn(x[n,c,2oy,2ox])): the pre-activation of a stride-2 1x1 projection only
 // needs every other row and column.  One lane = 2 adjacent outputs (one float4 of input).
 __global__ void __launch_bounds__(256)
@@ -237,6 +289,23 @@ extern "C" int dmn_dpn_merge(const float *base, const float *yv, float *out, flo
     else     { if (act) DMN_MERGE(1, true); else DMN_MERGE(1, false); }
 #undef DMN_MERGE
     return launch_status("dmn_dpn_merge");
+}
+
+extern "C" int dmn_dpn_stage_pass(float *buf, float *act, float *out,
+                                  const float *mean, const float *scale, const float *bias,
+                                  int N, int rows, int c1c, int inc, int Co, int HW, void *stream)
+{
+    if (!buf || !act || !mean || !scale || !bias) return fail(-1, "dmn_dpn_stage_pass: NULL pointer");
+    if (N <= 0 || HW <= 0 || c1c <= 0 || inc <= 0 || Co < c1c + 3 * inc || (Co - c1c - 2 * inc) % inc ||
+        rows < Co + inc)
+        return fail(-4, "dmn_dpn_stage_pass: bad sizes N=%d rows=%d c1c=%d inc=%d Co=%d HW=%d", N, rows, c1c, inc, Co, HW);
+    const bool vec = HW % 4 == 0 && !(((uintptr_t)buf | (uintptr_t)act | (uintptr_t)out) & 15);
+    const int hwv = vec ? HW / 4 : HW;
+    const long long total = (long long)N * Co * hwv;
+    hipStream_t s = (hipStream_t)stream;
+    if (vec) hipLaunchKernelGGL(dpn_stage_pass_kernel<4>, dim3(grid_for(total)), dim3(256), 0, s, buf, act, out, mean, scale, bias, total, rows, c1c, inc, Co, hwv);
+    else hipLaunchKernelGGL(dpn_stage_pass_kernel<1>, dim3(grid_for(total)), dim3(256), 0, s, buf, act, out, mean, scale, bias, total, rows, c1c, inc, Co, hwv);
+    return launch_status("dmn_dpn_stage_pass");
 }
 
 extern "C" int dmn_bn_relu_s2(const float *x, const float *mean, const float *scale, const float *bias,

@@ -68,6 +68,20 @@ def _gconv_weight(conv):
     return cached[1]
 
 
+def _proj_weight(conv, c1c):
+    """Projection weight (c1c + 2*inc, Cin) with its rows reordered to [dense0 | res]: the order
+    of the stage buffer (see ops.dpn_stage_pass); cached per weight version."""
+    w = conv.weight
+    key = (w._version, w.data_ptr(), c1c)
+    cached = conv.__dict__.get("_dmn_proj_w")
+    if cached is None or cached[0] != key:
+        with torch.no_grad():
+            w2 = w.detach().view(w.shape[0], w.shape[1])
+            cached = (key, torch.cat([w2[c1c:], w2[:c1c]], 0).contiguous())
+        conv.__dict__["_dmn_proj_w"] = cached
+    return cached[1]
+
+
 def _bn_relu(bn, x):
     return ops.bn_relu(x, *_bn_consts(bn))
 
@@ -153,6 +167,21 @@ class DualPathBlock(nn.Module):
             o1, o2 = y[:, :self.c1c], y[:, self.c1c:]
         return res + o1, torch.cat([dense, o2], dim=1)
 
+    def _y_path(self, act_a):
+        """relu(c1x1_c.bn(c3x3_b(c1x1_a.conv(act_a)))): everything of the block's main path up to
+        the input of its last 1x1 convolution."""
+        y = _conv(self.c1x1_a.conv, act_a)
+        conv_b = self.c3x3_b.conv
+        stride = conv_b.stride[0]
+        if (self.fuse_gconv and conv_b.in_channels // conv_b.groups in ops.GCONV_GROUP_WIDTHS
+                and (stride == 1 or (stride == 2 and y.shape[2] % 2 == 0 and y.shape[3] % 8 == 0))):
+            # bn + relu, grouped 3x3 conv, next bn + relu: one HBM-bound pass
+            y = ops.gconv3x3_bn_relu(y, _gconv_weight(conv_b), conv_b.groups,
+                                     _bn_consts(self.c3x3_b.bn), _bn_consts(self.c1x1_c.bn), stride)
+        else:
+            y = _bn_relu(self.c1x1_c.bn, conv_b(_bn_relu(self.c3x3_b.bn, y)))
+        return y
+
     def forward_fused(self, X, act_a, next_bn):
         """X: contiguous [residual | dense]; act_a: relu(c1x1_a.bn(X)) if the previous merge
         already produced it.  Returns (X', relu(next_bn(X')))."""
@@ -169,17 +198,7 @@ class DualPathBlock(nn.Module):
                 base = ops.conv1x1(ops.bn_relu_s2(X, *_bn_consts(w.bn)), w.conv.weight)
             else:
                 base = _conv(w.conv, _bn_relu(w.bn, X))
-        y = _conv(self.c1x1_a.conv, act_a)
-        conv_b = self.c3x3_b.conv
-        stride = conv_b.stride[0]
-        if (self.fuse_gconv and conv_b.in_channels // conv_b.groups in ops.GCONV_GROUP_WIDTHS
-                and (stride == 1 or (stride == 2 and y.shape[2] % 2 == 0 and y.shape[3] % 8 == 0))):
-            # bn + relu, grouped 3x3 conv, next bn + relu: one HBM-bound pass
-            y = ops.gconv3x3_bn_relu(y, _gconv_weight(conv_b), conv_b.groups,
-                                     _bn_consts(self.c3x3_b.bn), _bn_consts(self.c1x1_c.bn), stride)
-        else:
-            y = _bn_relu(self.c1x1_c.bn, conv_b(_bn_relu(self.c3x3_b.bn, y)))
-        y = _conv(self.c1x1_c.conv, y)
+        y = _conv(self.c1x1_c.conv, self._y_path(act_a))
         return ops.dpn_merge(base, y, self.c1c, _bn_consts(next_bn))
 
 
@@ -209,6 +228,7 @@ class DPN(nn.Module):
         self.features = nn.Sequential(blocks)
         self.fusable = not b
         self.fuse_glue = True          # set False to force the plain torch path
+        self.stage_inplace = True      # fused path: one in-place buffer per stage (False: dpn_merge per block)
 
     def _forward_fused(self, x):
         children = list(self.features.named_children())
@@ -223,12 +243,73 @@ class DPN(nn.Module):
             X = pool(_bn_relu(stem.bn, raw))
         feats = [raw]
         act = None
-        for i, (name, block) in enumerate(blocks):
-            nxt = blocks[i + 1][1].c1x1_a.bn if i + 1 < len(blocks) else final.bn
-            X, act = block.forward_fused(X, act, nxt)
-            if name in self.taps:
+        i = 0
+        while i < len(blocks):
+            j = i + 1
+            while j < len(blocks) and blocks[j][1].kind == "normal":
+                j += 1
+            nxt = blocks[j][1].c1x1_a.bn if j < len(blocks) else final.bn
+            if self.stage_inplace and self._stage_ok(blocks[i:j], X):
+                X, act = self._run_stage(blocks[i:j], X, act, nxt)
                 feats.append(X)
+            else:
+                for k in range(i, j):
+                    name, block = blocks[k]
+                    nb = blocks[k + 1][1].c1x1_a.bn if k + 1 < len(blocks) else final.bn
+                    X, act = block.forward_fused(X, act, nb)
+                    if name in self.taps:
+                        feats.append(X)
+            i = j
         return act, feats
+
+    def _stage_ok(self, stage, X):
+        """The in-place stage path needs: a projection block first, its output being a pyramid tap
+        (so only the stage's last block output is ever needed in reference order), plain 1x1
+        convolutions, and for a stride-2 projection the sizes dmn_bn_relu_s2 takes."""
+        first, last_name = stage[0][1], stage[-1][0]
+        if first.kind == "normal" or last_name not in self.taps:
+            return False
+        if any(n in self.taps for n, _ in stage[:-1]):
+            return False
+        w = first.c1x1_w_s2 if first.kind == "down" else first.c1x1_w_s1
+        if w.conv.kernel_size != (1, 1) or w.conv.bias is not None:
+            return False
+        if first.kind == "down" and (X.shape[2] % 2 or X.shape[3] % 4 or w.conv.stride != (2, 2)):
+            return False
+        return all(b.c1c == first.c1c and b.inc == first.inc and b.c1x1_c.conv.bias is None
+                   for _, b in stage)
+
+    def _run_stage(self, stage, X, act, next_bn):
+        """One DPN stage on ONE buffer per sample, rows [dense0 | res | slot | o2_1 | ...]: the
+        projection GEMM writes [dense0 | res], every block's last 1x1 convolution is a GEMM with
+        beta = 1 onto [res | slot] (the residual add is its epilogue) and ops.dpn_stage_pass writes
+        the next pre-activation; the residual and the old dense channels are never copied."""
+        first = stage[0][1]
+        c1c, inc, nb = first.c1c, first.inc, len(stage)
+        if act is None:
+            act = _bn_relu(first.c1x1_a.bn, X)
+        if first.kind == "down":
+            w = first.c1x1_w_s2
+            pin = ops.bn_relu_s2(X, *_bn_consts(w.bn))
+        else:
+            w = first.c1x1_w_s1
+            pin = _bn_relu(w.bn, X)
+        N, Cin, Hs, Ws = pin.shape
+        rows = c1c + 3 * inc + nb * inc
+        buf = torch.empty((N, rows, Hs, Ws), device=X.device, dtype=torch.float32)
+        buf3 = buf.view(N, rows, Hs * Ws)
+        buf3[:, 2 * inc + c1c:3 * inc + c1c].zero_()
+        ops.tuned_matmul(_proj_weight(w.conv, c1c), pin.view(N, Cin, Hs * Ws), out=buf3[:, :2 * inc + c1c])
+        res_slot = buf3[:, 2 * inc:3 * inc + c1c]
+        out = None
+        for m, (name, block) in enumerate(stage, 1):
+            y = block._y_path(act)
+            wc = block.c1x1_c.conv.weight
+            ops.tuned_matmul(wc.view(wc.shape[0], wc.shape[1]), y.view(N, y.shape[1], Hs * Ws), acc=res_slot)
+            bn = stage[m][1].c1x1_a.bn if m < nb else next_bn
+            act, out = ops.dpn_stage_pass(buf, c1c, inc, c1c + 2 * inc + m * inc, _bn_consts(bn),
+                                          want_out=(m == nb))
+        return out, act
 
     def forward(self, x):
         if (self.fuse_glue and self.fusable and not self.training

@@ -105,9 +105,10 @@ def _time_matmul(name, a, b, reps=3):
     return e0.elapsed_time(e1)
 
 
-def tuned_matmul(a, b, acc=None):
+def tuned_matmul(a, b, acc=None, out=None):
     """torch.matmul(a, b) (+ acc, accumulated in place, when given: a (M, K), b (B, K, N),
-    acc (B, M, N)) with the BLAS library (rocBLAS / hipBLASLt) chosen PER SHAPE: neither
+    acc (B, M, N); or written into `out` (B, M, N), which like acc may be a row-slice view of a
+    larger (B, rows, N) buffer: unit stride along N) with the BLAS library (rocBLAS / hipBLASLt) chosen PER SHAPE: neither
     wins everywhere on MI355X (profiles/r1_conv1x1_backend_probe.txt: hipBLASLt is 10-25 % faster
     on DPN92's conv2_x / conv4_x 1x1 shapes, rocBLAS on the others and on the mSRU projections).
     The choice is timed once per shape on first use (a few launches and one event wait; not
@@ -128,10 +129,12 @@ def tuned_matmul(a, b, acc=None):
                 choice = min(t, key=t.get)
                 _BMM_CHOICE[key] = choice
         torch.backends.cuda.preferred_blas_library(choice)
-        if acc is None:
-            out = torch.matmul(a, b)
-        else:
+        if acc is not None:
             out = torch.baddbmm(acc, a.unsqueeze(0).expand(b.shape[0], -1, -1), b, out=acc)
+        elif out is not None:
+            out = torch.baddbmm(out, a.unsqueeze(0).expand(b.shape[0], -1, -1), b, beta=0, out=out)
+        else:
+            out = torch.matmul(a, b)
     finally:
         torch.backends.cuda.preferred_blas_library(prev)
     return out
@@ -591,6 +594,22 @@ def gconv3x3_bn_relu(x, weight_t, groups, bn_in=None, bn_out=None, stride=1):
                   _ptr(b[0]), _ptr(b[1]), _ptr(b[2]), _ptr(y), N, C, H, W, int(groups), int(stride),
                   _stream())
     return y
+
+
+def dpn_stage_pass(buf, c1c, inc, Co, bn, want_out=False):
+    """In-place DPN stage buffer buf (N, rows, H, W) = [dense0 | res | slot | o2_1 ..] after the
+    beta = 1 GEMM onto [res | slot]: returns (act, out) with act (N, Co, H, W) = relu(bn(X)) in the
+    reference channel order and out = X itself when want_out (else None); moves the slot's
+    channels to their final rows and zeroes the slot (see dmn_dpn_stage_pass)."""
+    N, rows, H, W = buf.shape
+    _chk("dpn_stage_pass", buf)
+    _chk_bn("dpn_stage_pass", bn, Co)
+    with torch.cuda.device(buf.device):
+        act = torch.empty((N, Co, H, W), device=buf.device, dtype=torch.float32)
+        out = torch.empty_like(act) if want_out else None
+        _lib.call("dmn_dpn_stage_pass", _ptr(buf), _ptr(act), _ptr(out), _ptr(bn[0]), _ptr(bn[1]),
+                  _ptr(bn[2]), N, rows, int(c1c), int(inc), int(Co), H * W, _stream())
+    return act, out
 
 
 def dpn_merge(base, y, c1c, bn=None):

@@ -272,6 +272,20 @@ int dmn_dpn_merge(const float *base, const float *yv, float *out, float *act,
                   const float *mean, const float *scale, const float *bias,
                   int N, int Cb, int Cy, int c1c, int HW, void *stream);
 
+/*
+ * dmn_dpn_stage_pass: dmn_dpn_merge for a stage whose blocks share ONE buffer per sample
+ *   buf (N, rows, HW), rows >= Co + inc:  [ dense0 (2*inc) | res (c1c) | slot (inc) | o2_1 | o2_2 | ... ]
+ * The caller runs the block's last 1x1 convolution (dpn_model.py:262-264) as a library GEMM with
+ * beta = 1 onto rows [res | slot] (slot zeroed), so `resid = x_s1 + out1` (dpn_model.py:265-266) is the
+ * GEMM epilogue.  This pass writes act (N, Co, HW) = relu(bn(X)) with X in the reference's channel
+ * order [res | dense0 | o2_1 .. | slot] (dpn_model.py:246,267-269) for the (mean, scale, bias) of the
+ * next consumer, moves the slot's channels to their final rows [Co .. Co + inc), zeroes
+ * the slot, and writes X itself to out (N, Co, HW) when out != NULL (pyramid taps).
+ */
+int dmn_dpn_stage_pass(float *buf, float *act, float *out,
+                       const float *mean, const float *scale, const float *bias,
+                       int N, int rows, int c1c, int inc, int Co, int HW, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

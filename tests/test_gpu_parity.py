@@ -666,6 +666,34 @@ def test_grouped_conv3x3_rejects_unsupported_group_width():
         ops.gconv3x3_bn_relu(x, w, 2)
 
 
+@pytest.mark.parametrize("N,c1c,inc,k,H,W", [(2, 8, 2, 0, 4, 4), (1, 6, 3, 2, 3, 5), (2, 256, 16, 1, 8, 8), (1, 4, 1, 5, 1, 1)])
+@pytest.mark.parametrize("want_out", [False, True])
+def test_dpn_stage_pass_matches_reference_order_and_moves_the_slot(N, c1c, inc, k, H, W, want_out):
+    """In-place stage buffer [dense0 | res | slot | o2_1..]: the pass must emit relu(bn(X)) with X in
+    the reference's order [res | dense0 | o2_1..o2_k | slot], move the slot to its final rows and
+    zero it (dpn_model.py:246,265-269)."""
+    Co = c1c + 2 * inc + (k + 1) * inc
+    rows = Co + inc + 2 * inc                                  # room for two more blocks
+    buf = det_uniform((N, rows, H, W), 191, 1.0).to(DEV)
+    before = buf.clone()
+    mean, scale, bias = (det_uniform((Co,), 192 + i, 1.0).to(DEV) for i in range(3))
+    dense0, res = before[:, :2 * inc], before[:, 2 * inc:2 * inc + c1c]
+    slot = before[:, 2 * inc + c1c:3 * inc + c1c]
+    older = before[:, 3 * inc + c1c:3 * inc + c1c + k * inc]
+    X = torch.cat([res, dense0, older, slot], 1)
+    assert X.shape[1] == Co
+    act, out = ops.dpn_stage_pass(buf, c1c, inc, Co, (mean, scale, bias), want_out)
+    want = torch.relu((X - mean.view(1, -1, 1, 1)) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1))
+    assert rel_err(act, want) < 1e-6
+    assert (out is None) == (not want_out) and (out is None or torch.equal(out, X))
+    assert torch.equal(buf[:, Co:Co + inc], slot)                              # moved to its final rows
+    assert not buf[:, 2 * inc + c1c:3 * inc + c1c].any()                        # slot cleared
+    keep = torch.ones(rows, dtype=torch.bool)
+    keep[2 * inc + c1c:3 * inc + c1c] = False
+    keep[Co:Co + inc] = False
+    assert torch.equal(buf[:, keep], before[:, keep])                           # nothing else touched
+
+
 def test_dpn92_fused_glue_equals_plain_torch_backbone():
     """Same module, same weights: fast path (HIP glue) vs the plain torch path, all taps."""
     from dms_amd.models.dpn import DPN
@@ -681,6 +709,17 @@ def test_dpn92_fused_glue_equals_plain_torch_backbone():
     assert rel_err(out_f, out_t) < 1e-5
     for a, b in zip(feats_f, feats_t):
         assert a.shape == b.shape and rel_err(a, b) < 1e-5
+    # per-block dpn_merge instead of the in-place stage buffers; odd sizes take it by themselves
+    net.fuse_glue, net.stage_inplace = True, False
+    with torch.no_grad():
+        out_m, feats_m = net(img)
+        net.stage_inplace = True
+        odd = det_uniform((1, 3, 72, 88), 78, 1.0).to(DEV)     # 18x22 maps at conv2: W % 4 != 0 before conv3
+        out_o, feats_o = net(odd)
+        net.fuse_glue = False
+        out_ot, feats_ot = net(odd)
+    assert rel_err(out_m, out_t) < 1e-5 and all(rel_err(a, b) < 1e-5 for a, b in zip(feats_m, feats_t))
+    assert rel_err(out_o, out_ot) < 1e-5 and all(rel_err(a, b) < 1e-5 for a, b in zip(feats_o, feats_ot))
     # weights changed in place (load_state_dict) must invalidate the cached BN constants
     net.fuse_glue = True
     with torch.no_grad():
