@@ -87,6 +87,10 @@ class LaunchTimer(object):
         if name == "dmn_dynfilter_fwd":
             B, L, K, C, S = args[3:8]
             return "dynfilter_fwd", 4 * B * (C * S + L * K * C + L * K * S)
+        if name == "dmn_mix_sru_fwd":
+            B, L, K, S, d = args[9:14]
+            return ("mix+sru_fwd fused k=4 T=%d cols=%d (issue-bound)" % (S * L, B * d),
+                    4 * B * (S * 4 * d + L * 4 * d + L * K * S + S * L * d))
         if name == "dmn_mix_bcast_add":
             B, L, K, S, M = args[6:11]
             return "mix_bcast_add", 4 * B * (S * M + L * M + L * K * S + S * L * M)

@@ -28,6 +28,7 @@ SIGNATURES = {
     "dmn_dynfilter_fwd": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
     "dmn_dynfilter_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "dmn_mix_bcast_add": [_p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p],
+    "dmn_mix_sru_fwd": [_p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "dmn_mix_bcast_add_bwd": [_p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "dmn_cat_upsample2x": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
     "dmn_cat_upsample2x_bwd": [_p, _p, _p, _i, _i, _i, _i, _i, _p],

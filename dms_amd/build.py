@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libdmn_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = ["abi.hip", "sru.hip", "sru_fwd_k2.hip", "sru_fwd_k3.hip", "sru_fwd_k4.hip", "dynfilter.hip", "mix.hip", "glue.hip", "wino.hip", "tapconv.hip", "metrics.hip", "dpn_glue.hip", "gconv.hip"]
+SOURCES = ["abi.hip", "sru.hip", "sru_fwd_k2.hip", "sru_fwd_k3.hip", "sru_fwd_k4.hip", "dynfilter.hip", "mix.hip", "mix_sru.hip", "glue.hip", "wino.hip", "tapconv.hip", "metrics.hip", "dpn_glue.hip", "gconv.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

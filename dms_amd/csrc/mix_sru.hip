@@ -1,0 +1,181 @@
+// dms_amd/csrc/mix_sru.hip -- concat-free mix FUSED into the mSRU layer-0 scan (gfx950, inference).
+//
+// With comb_conv folded into the layer-0 projection (dmn.py:192 followed by the `x.mm(weight)` of
+// the first SRUCell under dmn.py:204) the layer-0 pre-activations are
+//     U0[(s*L + t), b, j, g] = A[b,s,4j+g] + Bt[t,b,4j+g] + sum_k Wp[4j+g,k] * P[t,b,k,s]
+// dmn_mix_bcast_add writes that tensor (16 B per element, 2.6 GB at B=32 / 512 px) and dmn_sru_fwd
+// reads it back once.  Here the scan lane that owns column (b, j) builds its four gate values of a
+// step in registers and consumes them on the spot: U0 is never stored.  What is left in memory
+// traffic is A (read once), the per-word rows Bt (kept per lane in LDS), P (wave-uniform: staged
+// through LDS a pixel ahead, read back as broadcasts) and the h store -- the kernel is bound by one wave's in-order issue (~230 cycles per step:
+// 10 x 4 FMAs on top of the scan's 17 operations), not by HBM, and beats the two-kernel path
+// once there are enough columns to occupy the SIMDs (the caller decides).
+//
+// The arithmetic repeats dmn_mix_bcast_add's and dmn_sru_fwd's operation for operation (same
+// order of the additions and FMAs, same gate formulas), so h is bit-identical to the unfused path.
+#include "common.h"
+
+namespace dmn {
+
+constexpr float MS_LOG2E = 1.4426950408889634f;
+
+// One 64-lane workgroup = 64 adjacent columns j of ONE sample b (so P is wave-uniform).
+// Pt: P transposed to (B, S, L, K) so that the L*K values of a pixel are adjacent.
+// KX > 0: K == KX exactly (unrolled); KX == 0: runtime K <= 16.
+template <int ACT, int KX>
+__global__ void __launch_bounds__(WAVE)
+mix_sru_fwd_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
+                   const float *__restrict__ Pt, const float *__restrict__ Wp, int ldw,
+                   const float *__restrict__ bias, const float *__restrict__ c0,
+                   float *__restrict__ h, float *__restrict__ c_last,
+                   int B, int L, int K, int S, int d)
+{
+    extern __shared__ float4 bt_lds[];                        // [L][64]: this lane's Bt rows
+    constexpr int KR = KX > 0 ? KX : 16;
+    const int b = blockIdx.y;
+    // lanes past the last column stay alive (they carry their share of the P staging below) on the
+    // CLAMPED column d-1: same inputs, same arithmetic, so they store the same bits to the same
+    // addresses as the lane that owns it -- benign, and no exec masking in the loop
+    const int jr = blockIdx.x * WAVE + threadIdx.x;
+    const int j = jr < d ? jr : d - 1;
+    const int M4 = 4 * d;
+    const int col = b * d + j;
+
+    // gate pairs (u0, forget) and (reset, highway) ride one v_pk_fma_f32 each per filter
+    f32x2_t w01[KR], w23[KR];
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+        const bool on = KX > 0 || k < K;
+        w01[k] = (f32x2_t){on ? Wp[(long long)(4 * j + 0) * ldw + k] : 0.0f, on ? Wp[(long long)(4 * j + 1) * ldw + k] : 0.0f};
+        w23[k] = (f32x2_t){on ? Wp[(long long)(4 * j + 2) * ldw + k] : 0.0f, on ? Wp[(long long)(4 * j + 3) * ldw + k] : 0.0f};
+    }
+    for (int t = 0; t < L; ++t)
+        bt_lds[t * WAVE + threadIdx.x] =
+            *reinterpret_cast<const float4 *>(Bt + ((long long)t * B + b) * M4 + 4 * j);
+
+    const float bf2 = -MS_LOG2E * bias[j], br2 = -MS_LOG2E * bias[j + d];
+    float cur = c0 ? c0[col] : 0.0f;
+    const float *Ap = A + (long long)b * S * M4 + 4 * j;
+    const float *pb = Pt + (long long)b * S * L * K;          // uniform
+    float *hp = h + col;
+    const long long hstride = (long long)B * d;
+    // Per pixel the lane needs A[b,s,4j..] (16 B) and the wave needs P[b,s] (L*K values, uniform).
+    // Both are fetched one PIXEL ahead.  Two measured dead ends shape how:
+    //  * P through scalar loads: SMEM returns out of order, every wait is lgkmcnt(0), the
+    //    look-ahead collapses to one step (580 cycles per step);
+    //  * compiler-visible vector loads: vmcnt also counts the h stores on gfx9 and hipcc's waits
+    //    for the prefetched registers land in the per-step path (`s_waitcnt vmcnt(1)` = wait for
+    //    the previous step's store to be acknowledged; again ~580 cycles per step).
+    // So, as in sru_fwd.inl, the prefetch loads are inline asm that hipcc does not count and are
+    // waited for once per pixel with an exact counted vmcnt(N), N = the h stores issued since.
+    // P goes registers -> LDS (padded, unconditional) and is read back as broadcasts.
+    const int LK = L * K;
+    constexpr int PREG = 4, PBUF = PREG * WAVE;                // LK <= 256 (checked by the host)
+    float *p_lds = reinterpret_cast<float *>(bt_lds + (size_t)L * WAVE);     // [2][PBUF]
+    unsigned poff[PREG];
+#pragma unroll
+    for (int i = 0; i < PREG; ++i) {
+        const int idx = i * WAVE + (int)threadIdx.x;
+        poff[i] = (unsigned)(idx < LK ? idx : LK - 1) * 4u;
+    }
+    const unsigned aoff = (unsigned)(4 * j) * 4u;
+    const float *Ab = A + (long long)b * S * M4;               // uniform bases
+    f32x4_t a_nx = {0.0f, 0.0f, 0.0f, 0.0f};
+    float pre[PREG] = {0.0f, 0.0f, 0.0f, 0.0f};
+    auto fetch_pixel = [&](int sp) {
+        const int sc = sp < S ? sp : S - 1;
+        const float *asrc = Ab + (long long)sc * M4;
+        const float *psrc = pb + (long long)sc * LK;
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(a_nx) : "v"(aoff), "s"(asrc) : "memory");
+#pragma unroll
+        for (int i = 0; i < PREG; ++i)
+            asm volatile("global_load_dword %0, %1, %2" : "+v"(pre[i]) : "v"(poff[i]), "s"(psrc) : "memory");
+    };
+    // wait until at most N younger VMEM operations (the h stores since the fetch) are outstanding
+#define DMN_MS_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(a_nx), "+v"(pre[0]), "+v"(pre[1]), "+v"(pre[2]), "+v"(pre[3]) : : "memory")
+    fetch_pixel(0);
+    DMN_MS_WAIT(0);
+    int buf = 0;
+    for (int s = 0; s < S; ++s) {
+        const float4 ac = make_float4(a_nx.x, a_nx.y, a_nx.z, a_nx.w);
+#pragma unroll
+        for (int i = 0; i < PREG; ++i) p_lds[buf * PBUF + i * WAVE + (int)threadIdx.x] = pre[i];
+        fetch_pixel(s + 1);
+        const float *pl = p_lds + buf * PBUF;
+        float pn[KR];
+#pragma unroll
+        for (int k = 0; k < KR; ++k) pn[k] = (KX > 0 || k < K) ? pl[k] : 0.0f;
+        float4 btn = bt_lds[threadIdx.x];
+        float *hs = hp + (long long)s * L * hstride;
+#pragma unroll 2
+        for (int t = 0; t < L; ++t) {
+            float pv[KR];
+#pragma unroll
+            for (int k = 0; k < KR; ++k) pv[k] = pn[k];
+            const float4 bt = btn;
+            const int tn = t + 1 < L ? t + 1 : t;             // next step's operands (last: re-read)
+#pragma unroll
+            for (int k = 0; k < KR; ++k) pn[k] = (KX > 0 || k < K) ? pl[tn * K + k] : 0.0f;
+            btn = bt_lds[tn * WAVE + threadIdx.x];
+            // (a sched_barrier here to pin the LDS reads a full step ahead: measured slower, 0.85 vs 0.78 ms)
+            f32x2_t q01 = {ac.x + bt.x, ac.y + bt.y}, q23 = {ac.z + bt.z, ac.w + bt.w};
+#pragma unroll
+            for (int k = 0; k < KR; ++k) {
+                if (KX > 0 || k < K) {
+                    q01 = __builtin_elementwise_fma(w01[k], (f32x2_t){pv[k], pv[k]}, q01);
+                    q23 = __builtin_elementwise_fma(w23[k], (f32x2_t){pv[k], pv[k]}, q23);
+                }
+            }
+            const float q[4] = {q01.x, q01.y, q23.x, q23.y};
+            // SRU step (k = 4): q = [u0, forget, reset, highway]
+            const float f = fast_rcp(1.0f + fast_exp2(__builtin_fmaf(q[1], -MS_LOG2E, bf2)));
+            const float r = fast_rcp(1.0f + fast_exp2(__builtin_fmaf(q[2], -MS_LOG2E, br2)));
+            cur = __builtin_fmaf(cur - q[0], f, q[0]);
+            const float hv = __builtin_fmaf(act_fwd<ACT>(cur) - q[3], r, q[3]);
+            __builtin_nontemporal_store(hv, hs + (long long)t * hstride);
+        }
+        // the L stores above are younger than the fetch: leave (at most) that many outstanding
+        if (L >= 20) DMN_MS_WAIT(20);
+        else if (L >= 8) DMN_MS_WAIT(8);
+        else DMN_MS_WAIT(0);
+        buf ^= 1;
+    }
+#undef DMN_MS_WAIT
+    if (c_last) c_last[col] = cur;
+}
+
+}  // namespace dmn
+
+using namespace dmn;
+
+extern "C" int dmn_mix_sru_fwd(const float *A, const float *Bt, const float *Pt, const float *Wp,
+                               int ldw, const float *bias, const float *c0, float *h, float *c_last,
+                               int B, int L, int K, int S, int d, int act, void *stream)
+{
+    if (!A || !Bt || !Pt || !Wp || !bias || !h) return fail(-1, "dmn_mix_sru_fwd: NULL pointer");
+    if (B <= 0 || L <= 0 || K <= 0 || S <= 0 || d <= 0 || ldw < K)
+        return fail(-4, "dmn_mix_sru_fwd: bad sizes B=%d L=%d K=%d S=%d d=%d ldw=%d", B, L, K, S, d, ldw);
+    if (K > 16) return fail(-5, "dmn_mix_sru_fwd: K=%d > 16 not supported (use dmn_mix_bcast_add + dmn_sru_fwd)", K);
+    if (B > 65535) return fail(-5, "dmn_mix_sru_fwd: B=%d exceeds the grid y limit", B);
+    if (((uintptr_t)A | (uintptr_t)Bt) & 15) return fail(-7, "dmn_mix_sru_fwd: A and Bt must be 16-byte aligned");
+    if (L * K > 256) return fail(-5, "dmn_mix_sru_fwd: L*K=%d > 256 not supported", L * K);
+    const size_t lds = (size_t)L * WAVE * sizeof(float4) + 2 * 4 * WAVE * sizeof(float);
+    if (lds > 64 * 1024) return fail(-5, "dmn_mix_sru_fwd: L=%d too large for the LDS stage", L);
+    if (act != DMN_ACT_TANH && act != DMN_ACT_RELU && act != DMN_ACT_IDENTITY)
+        return fail(-2, "dmn_mix_sru_fwd: unknown activation %d", act);
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((d + WAVE - 1) / WAVE, B);
+#define DMN_MS(ACTV, KXV) hipLaunchKernelGGL((mix_sru_fwd_kernel<ACTV, KXV>), grid, dim3(WAVE), lds, s, A, Bt, Pt, \
+                                             Wp, ldw, bias, c0, h, c_last, B, L, K, S, d)
+#define DMN_MSA(KXV)                                                \
+    do {                                                            \
+        if (act == DMN_ACT_TANH) DMN_MS(DMN_ACT_TANH, KXV);         \
+        else if (act == DMN_ACT_RELU) DMN_MS(DMN_ACT_RELU, KXV);    \
+        else DMN_MS(DMN_ACT_IDENTITY, KXV);                         \
+    } while (0)
+    if (K == 10) DMN_MSA(10);
+    else DMN_MSA(0);
+#undef DMN_MSA
+#undef DMN_MS
+    return launch_status("dmn_mix_sru_fwd");
+}

@@ -32,6 +32,12 @@ from ..sru import SRU
 from .dpn import create_backbone
 
 
+# ops.mix_sru_fwd is issue-bound (~0.8 ms at T = 5120 however few columns), the mix + scan pair is
+# HBM-bound and shrinks with the batch: measured cross-over on MI355X (tools/mix_sru_bench.py)
+# near 20 samples of 1005 columns (B=16: 0.68 vs 0.81 ms, B=32: 1.41 vs 0.90, B=64: 2.90 vs 1.27)
+MIX_SCAN_MIN_COLS = 20000
+
+
 def _lenient_load(module, new_state, verbose=False):
     """Copy same-name, same-size tensors; ignore the rest (dmn.py:217-223)."""
     state = module.state_dict()
@@ -64,6 +70,9 @@ class BaseDMN(nn.Module):
         # inference-time algebraic fold of comb_conv into the mSRU layer-0 projection
         # (see _folded_weights); set to False to run the unfused path
         self.fold_comb_into_msru = True
+        # with the fold: mix fused into the layer-0 scan (ops.mix_sru_fwd) when the batch is large
+        # enough for it to win (MIX_SCAN_MIN_COLS columns); False = mix kernel + scan kernel
+        self.fuse_mix_scan = True
         self._fold_cache = None
         self.base = create_backbone(backend, pretrained=pretrained, extra=extra)
 
@@ -119,8 +128,14 @@ class BaseDMN(nn.Module):
             Wv_f, Wl_f, Wp_f, b_f = self._folded_weights()
             A = ops.tuned_matmul(V.transpose(1, 2), Wv_f)           # (B, S, 4*Hm)
             Bt = torch.addmm(b_f, lang_cat, Wl_f).view(L, B, -1)    # (L, B, 4*Hm)
-            U0 = ops.mix_bcast_add(A, Bt, P, Wp_f)                  # (S*L, B, 4*Hm) = layer-0 U
-            out, _ = self.mrnn(U0, tail=S, projected=True)
+            cell0 = self.mrnn.rnn_lst[0]
+            if (self.fuse_mix_scan and K <= 16 and B * cell0.n_out >= MIX_SCAN_MIN_COLS):
+                # enough columns to occupy the SIMDs: the scan lanes build U0 themselves
+                h0, c0_last = ops.mix_sru_fwd(A, Bt, P, Wp_f, cell0.bias, None, cell0.activation)
+                out, _ = self.mrnn(h0, tail=S, first_done=c0_last)
+            else:
+                U0 = ops.mix_bcast_add(A, Bt, P, Wp_f)              # (S*L, B, 4*Hm) = layer-0 U
+                out, _ = self.mrnn(U0, tail=S, projected=True)
             out = out.permute(1, 2, 0).contiguous().view(B, -1, H, W)
             if not self.high_res:
                 oc = self.output_collapse                              # dmn.py:213-214

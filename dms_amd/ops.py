@@ -361,6 +361,29 @@ def mix_bcast_add(A, Bt, P, Wp):
 # ------------------------------------------------------------------------------------
 # cat + bilinear x2
 # ------------------------------------------------------------------------------------
+def mix_sru_fwd(A, Bt, P, Wp, bias, c0=None, act="tanh"):
+    """mix_bcast_add fused into the layer-0 scan (inference, folded comb_conv, k = 4):
+    A (B, S, 4d), Bt (L, B, 4d), P (L, B, K, S), Wp (4d, K) (a column slice is fine), bias (2d)
+    -> h (S*L, B, d), c_last (B, d); bit-identical to sru_forward_raw(mix_bcast_add(...))."""
+    B, S, M4 = A.shape
+    L, _, K, _ = P.shape
+    d = M4 // 4
+    _chk("mix_sru_fwd", A, (B, S, 4 * d))
+    _chk("mix_sru_fwd", Bt, (L, B, 4 * d))
+    _chk("mix_sru_fwd", P, (L, B, K, S))
+    _chk("mix_sru_fwd", bias, (2 * d,))
+    _chk("mix_sru_fwd", c0, (B, d) if c0 is not None else None)
+    if Wp.shape != (4 * d, K) or Wp.stride(1) != 1 or not Wp.is_cuda or Wp.dtype != torch.float32:
+        raise RuntimeError("dms_amd.mix_sru_fwd: Wp must be a float32 ROCm (4d, K) matrix with unit column stride")
+    with torch.cuda.device(A.device):
+        Pt = P.permute(1, 3, 0, 2).contiguous()                   # (B, S, L, K): a pixel's L*K values adjacent
+        h = torch.empty((S * L, B, d), device=A.device, dtype=torch.float32)
+        c_last = torch.empty((B, d), device=A.device, dtype=torch.float32)
+        _lib.call("dmn_mix_sru_fwd", _ptr(A), _ptr(Bt), _ptr(Pt), _ptr(Wp), int(Wp.stride(0)), _ptr(bias),
+                  _ptr(c0), _ptr(h), _ptr(c_last), B, L, K, S, d, ACT_IDS[act], _stream())
+    return h, c_last
+
+
 class _CatUpsample2x(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, feat):

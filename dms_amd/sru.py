@@ -117,11 +117,13 @@ class SRU(nn.Module):
         for cell in self.rnn_lst:
             cell.set_bias(bias_val)
 
-    def forward(self, input, c0=None, return_hidden=True, tail=None, projected=False):
+    def forward(self, input, c0=None, return_hidden=True, tail=None, projected=False, first_done=None):
         """``tail=n`` (extension): only the last n steps of the LAST layer's h are produced
         (what dmn.py:209 keeps), so the final scan stores S instead of S*L rows.
         ``projected=True`` (extension): ``input`` is already layer 0's U = x.W,
-        shape (len, B, hidden*4); layer 0 must be a k = 4 cell."""
+        shape (len, B, hidden*4); layer 0 must be a k = 4 cell.
+        ``first_done=c_last`` (extension): ``input`` is already layer 0's hidden sequence (the
+        caller ran layer 0 itself, e.g. ops.mix_sru_fwd) and c_last its final cell state."""
         if input.dim() != 3:
             raise ValueError("SRU expects (len, batch, n_in), got %s" % (tuple(input.shape),))
         T = input.shape[0]
@@ -130,7 +132,11 @@ class SRU(nn.Module):
         for i, cell in enumerate(self.rnn_lst):
             last = i == self.depth - 1
             h_t0 = max(T - int(tail), 0) if (last and tail is not None) else 0
-            if i == 0 and projected:
+            if i == 0 and first_done is not None:
+                c = first_done
+                if last and h_t0:
+                    prev = prev[h_t0:]
+            elif i == 0 and projected:
                 prev, c = cell.forward_projected(prev, c0s[i], h_t0)
             else:
                 prev, c = cell(prev, c0s[i], h_t0)

@@ -133,6 +133,23 @@ int dmn_mix_bcast_add(const float *A, const float *Bt, const float *P, const flo
                       int ldw, float *Q, int B, int L, int K, int S, int M, void *stream);
 
 /*
+ * dmn_mix_bcast_add fused into the mSRU layer-0 scan (inference).  Replaces the same reference lines
+ * as dmn_mix_bcast_add (dmn.py:187-201) plus the first SRUCell's scan under dmn.py:204, for the case
+ * where comb_conv has been folded into that cell's projection (M = 4*d, k = 4): the lane that scans
+ * column (b, j) builds its four pre-activations
+ *   U0[(s*L + t), b, j, 0..3] = A[b,s,4j..] + Bt[t,b,4j..] + sum_k Wp[4j.., k] * P[t,b,k,s]
+ * in registers, so U0 (16 B per element) is never written or read.  Operation for operation the
+ * arithmetic of dmn_mix_bcast_add followed by dmn_sru_fwd: h is bit-identical to that pair.
+ *   A (B, S, 4d), Bt (L, B, 4d) 16-byte aligned; Pt (B, S, L, K) = P transposed by the caller (K <= 16);
+ *   Wp (4d, K) row stride ldw; bias (2d); c0 (B, d) or NULL; h (S*L, B, d); c_last (B, d) or NULL.
+ * Bound by one wave's instruction issue (~230 cycles per step), not by HBM: worth it from ~200
+ * wavefronts of columns (B*d/64) on; below that the two-kernel path with its time-parallel scan wins.
+ */
+int dmn_mix_sru_fwd(const float *A, const float *Bt, const float *Pt, const float *Wp, int ldw,
+                    const float *bias, const float *c0, float *h, float *c_last,
+                    int B, int L, int K, int S, int d, int act, void *stream);
+
+/*
  * gradients of dmn_mix_bcast_add w.r.t. A, Bt, P, Wp given gQ (S*L, B, M):
  *   gA[b,s,m] = sum_t gQ ; gBt[t,b,m] = sum_s gQ ; gP[t,b,k,s] = sum_m Wp[m,k] gQ ;
  *   gWp_part (L, B, M, K) partial sums per (word, batch entry) (caller reduces over L, B).

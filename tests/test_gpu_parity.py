@@ -325,12 +325,46 @@ def test_hot_path_matches_reference_golden(name):
         assert agree >= 0.999
 
 
+@pytest.mark.parametrize("B,L,K,S,d", [(2, 20, 10, 100, 1005), (1, 5, 3, 12, 7), (3, 4, 1, 7, 70), (2, 6, 10, 9, 64),
+                                       (1, 3, 16, 5, 130), (2, 1, 10, 1, 5)])
+@pytest.mark.parametrize("act", ["tanh", "relu"])
+def test_mix_fused_into_layer0_scan_is_bit_identical_to_mix_then_scan(B, L, K, S, d, act):
+    """dmn_mix_sru_fwd == dmn_sru_fwd(dmn_mix_bcast_add(...)) bit for bit (h and c_last), with and
+    without an initial state, and both match the CPU oracle on the einsum-built U0."""
+    M4 = 4 * d
+    A = det_uniform((B, S, M4), 201, 1.0).to(DEV)
+    Bt = det_uniform((L, B, M4), 202, 1.0).to(DEV)
+    P = det_uniform((L, B, K, S), 203, 1.0).to(DEV)
+    Wfull = det_uniform((M4, K + 3), 204, 0.5).to(DEV)
+    Wp = Wfull[:, 2:2 + K]                                     # a column slice: ldw > K
+    bias = det_uniform((2 * d,), 205, 0.5).to(DEV)
+    c0 = det_uniform((B, d), 206, 1.0).to(DEV)
+    for init in (None, c0):
+        U0 = ops.mix_bcast_add(A, Bt, P, Wp).view(S * L, B, d, 4)
+        h_ref, _, c_ref = ops.sru_forward_raw(U0, None, bias, init, act, 1.0, nchunks=1)
+        h, c = ops.mix_sru_fwd(A, Bt, P, Wp, bias, init, act)
+        assert h.shape == (S * L, B, d) and torch.equal(h, h_ref) and torch.equal(c, c_ref)
+    want = (A.permute(1, 0, 2)[:, None] + Bt[None] + torch.einsum("mk,tbks->stbm", Wp, P)).reshape(S * L, B, d, 4)
+    h_o, _, c_o = sru_ref.sru_fwd_c(want.cpu().numpy(), None, bias.cpu().numpy(), c0.cpu().numpy(), act, 1.0)
+    np.testing.assert_allclose(h.cpu().numpy(), h_o, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(c.cpu().numpy(), c_o, rtol=1e-4, atol=1e-5)
+
+
 def test_folded_layer0_projection_equals_unfused_path():
     """comb_conv folded into the mSRU layer-0 projection (inference) vs the unfused path."""
     net, vis, lang, g, cfg, _ = _product_base("base_full_320_lowres")
     with torch.no_grad():
         assert net.fold_comb_into_msru and net.mrnn.rnn_lst[0].k == 4
         a = net.hot_path(vis.to(DEV), lang.to(DEV)).cpu()
+        # the same with the mix fused into the layer-0 scan (taken by itself from ~12 samples on)
+        import dms_amd.models.dmn as dmn_mod
+        keep = dmn_mod.MIX_SCAN_MIN_COLS
+        dmn_mod.MIX_SCAN_MIN_COLS = 0
+        try:
+            a2 = net.hot_path(vis.to(DEV), lang.to(DEV)).cpu()
+        finally:
+            dmn_mod.MIX_SCAN_MIN_COLS = keep
+        assert rel_err(a2, a) < 1e-5       # (bit-identical only vs the un-chunked scan; B=1 runs the time-parallel one)
         net.fold_comb_into_msru = False
         b = net.hot_path(vis.to(DEV), lang.to(DEV)).cpu()
         # cache follows in-place weight updates

@@ -1,0 +1,39 @@
+"""Layer 0 of the mSRU with the folded comb_conv: mix kernel + scan kernel vs the fused kernel."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from dms_amd import ops
+
+dev = "cuda"
+L, K, S, d = 20, 10, 256, 1005
+
+
+def timeit(fn, iters=10):
+    for _ in range(2):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+for B in (4, 8, 12, 16, 32, 64):
+    A = torch.randn(B, S, 4 * d, device=dev)
+    Bt = torch.randn(L, B, 4 * d, device=dev)
+    P = torch.randn(L, B, K, S, device=dev)
+    W = torch.randn(4 * d, K, device=dev) * 0.1
+    bias = torch.randn(2 * d, device=dev) * 0.1
+
+    def pair():
+        u = ops.mix_bcast_add(A, Bt, P, W).view(S * L, B, d, 4)
+        return ops.sru_forward_raw(u, None, bias, None, "tanh", 1.0)
+
+    t_pair = timeit(pair)
+    t_fused = timeit(lambda: ops.mix_sru_fwd(A, Bt, P, W, bias, None, "tanh"))
+    print("B=%2d: mix + scan %.3f ms   fused %.3f ms" % (B, t_pair, t_fused), flush=True)
+    del A, Bt, P, W
