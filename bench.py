@@ -148,14 +148,30 @@ class LaunchTimer(object):
             return "dpn merge+bn_relu (all shapes)", 4 * N * HW * (Cb + Cy + Co * (2 if args[3] else 1))
         return name, 0
 
+    @staticmethod
+    def flops(name, args):
+        """fp32 flops of a launch for the kernels whose arithmetic intensity puts them above the
+        HBM ridge (reported next to the HBM fraction so that it is not misread), else 0."""
+        if name == "dmn_gconv3x3_bn_relu":
+            N, C, H, W, groups, st = args[9:15]
+            return 2 * N * C * (H // st) * (W // st) * (C // groups) * 9
+        if name == "dmn_dynfilter_fwd":
+            B, L, K, C, S = args[3:8]
+            return 2 * B * L * K * C * S
+        if name == "dmn_mix_sru_fwd":
+            B, L, K, S, d = args[9:14]
+            return 2 * B * S * L * d * 4 * K
+        return 0
+
     def summary(self):
         agg = {}
         for name, args, a, b in self.records:
             label, nbytes = self.describe(name, args)
-            e = agg.setdefault(label, {"calls": 0, "ms": 0.0, "bytes": 0})
+            e = agg.setdefault(label, {"calls": 0, "ms": 0.0, "bytes": 0, "flops": 0})
             e["calls"] += 1
             e["ms"] += a.elapsed_time(b)
             e["bytes"] += nbytes
+            e["flops"] += self.flops(name, args)
         out = []
         for label, e in agg.items():
             avg_ms = e["ms"] / e["calls"]
@@ -164,6 +180,10 @@ class LaunchTimer(object):
                         "total_ms": round(e["ms"], 3),
                         "algorithmic_bytes_per_launch": e["bytes"] // e["calls"],
                         "achieved_GBs": round(gbs, 1), "frac_of_8TBs": round(gbs / HBM_PEAK_GBS, 4)})
+            if e["flops"]:
+                tf = e["flops"] / (e["ms"] * 1e-3) / 1e12
+                out[-1].update({"achieved_TFLOPs": round(tf, 1), "frac_of_157TF_fp32": round(tf / 157.0, 4),
+                                "bound": "fp32 issue (above the HBM ridge)"})
         out.sort(key=lambda r: -r["total_ms"])
         return out
 
@@ -359,7 +379,7 @@ def main():
                     help="(image, query) pairs per GPU (default 32; 64 for train320)")
     ap.add_argument("--workload", default="dmn512", choices=["dmn512", "msru_stress", "train320"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-reps", type=int, default=5)
+    ap.add_argument("--cpu-reps", type=int, default=25)
     ap.add_argument("--no-gemm-table", action="store_true",
                     help="do not load the recorded per-shape BLAS solution table (dms_amd/tuning/)")
     args = ap.parse_args()

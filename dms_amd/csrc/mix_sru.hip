@@ -19,10 +19,23 @@ namespace dmn {
 
 constexpr float MS_LOG2E = 1.4426950408889634f;
 
+template <int I> struct TC { static constexpr int value = I; };
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for_t(F &&f)
+{
+    if constexpr (I < N) {
+        f(TC<I>{});
+        static_for_t<I + 1, N>(f);
+    }
+}
+
 // One 64-lane workgroup = 64 adjacent columns j of ONE sample b (so P is wave-uniform).
 // Pt: P transposed to (B, S, L, K) so that the L*K values of a pixel are adjacent.
 // KX > 0: K == KX exactly (unrolled); KX == 0: runtime K <= 16.
-template <int ACT, int KX>
+// LX > 0: L == LX exactly -- the word loop is fully unrolled and P never goes through LDS: the
+// pixel's L*K values stay spread over the lanes' prefetch registers and each step pulls its K
+// values into scalar registers with v_readlane (constant lane index), no memory wait at all.
+template <int ACT, int KX, int LX>
 __global__ void __launch_bounds__(WAVE)
 mix_sru_fwd_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
                    const float *__restrict__ Pt, const float *__restrict__ Wp, int ldw,
@@ -93,11 +106,43 @@ mix_sru_fwd_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
     };
     // wait until at most N younger VMEM operations (the h stores since the fetch) are outstanding
 #define DMN_MS_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(a_nx), "+v"(pre[0]), "+v"(pre[1]), "+v"(pre[2]), "+v"(pre[3]) : : "memory")
+    // LX path: with at most one wave per SIMD occupancy is moot, so the lane's L rows of Bt live in
+    // registers (4*LX VGPRs) and the step loop touches no memory but the h store
+    float4 btr[LX > 0 ? LX : 1];
+    if constexpr (LX > 0) {
+#pragma unroll
+        for (int t = 0; t < LX; ++t) btr[t] = bt_lds[t * WAVE + threadIdx.x];
+    }
     fetch_pixel(0);
     DMN_MS_WAIT(0);
     int buf = 0;
     for (int s = 0; s < S; ++s) {
         const float4 ac = make_float4(a_nx.x, a_nx.y, a_nx.z, a_nx.w);
+        if constexpr (LX > 0 && KX > 0) {
+            float hold[PREG];                                 // this pixel's P while the next one loads
+#pragma unroll
+            for (int i = 0; i < PREG; ++i) hold[i] = pre[i];
+            fetch_pixel(s + 1);
+            float *hs = hp + (long long)s * LX * hstride;
+            static_for_t<0, LX>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                const float4 bt = btr[t];
+                f32x2_t q01 = {ac.x + bt.x, ac.y + bt.y}, q23 = {ac.z + bt.z, ac.w + bt.w};
+#pragma unroll
+                for (int k = 0; k < KX; ++k) {
+                    const int idx = t * KX + k;
+                    const float pv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(
+                        __builtin_bit_cast(int, hold[idx / WAVE]), idx % WAVE));
+                    q01 = __builtin_elementwise_fma(w01[k], (f32x2_t){pv, pv}, q01);
+                    q23 = __builtin_elementwise_fma(w23[k], (f32x2_t){pv, pv}, q23);
+                }
+                const float f = fast_rcp(1.0f + fast_exp2(__builtin_fmaf(q01.y, -MS_LOG2E, bf2)));
+                const float r = fast_rcp(1.0f + fast_exp2(__builtin_fmaf(q23.x, -MS_LOG2E, br2)));
+                cur = __builtin_fmaf(cur - q01.x, f, q01.x);
+                const float hv = __builtin_fmaf(act_fwd<ACT>(cur) - q23.y, r, q23.y);
+                __builtin_nontemporal_store(hv, hs + (long long)t * hstride);
+            });
+        } else {
 #pragma unroll
         for (int i = 0; i < PREG; ++i) p_lds[buf * PBUF + i * WAVE + (int)threadIdx.x] = pre[i];
         fetch_pixel(s + 1);
@@ -134,6 +179,7 @@ mix_sru_fwd_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
             const float hv = __builtin_fmaf(act_fwd<ACT>(cur) - q[3], r, q[3]);
             __builtin_nontemporal_store(hv, hs + (long long)t * hstride);
         }
+        }
         // the L stores above are younger than the fetch: leave (at most) that many outstanding
         if (L >= 20) DMN_MS_WAIT(20);
         else if (L >= 8) DMN_MS_WAIT(8);
@@ -165,16 +211,17 @@ extern "C" int dmn_mix_sru_fwd(const float *A, const float *Bt, const float *Pt,
         return fail(-2, "dmn_mix_sru_fwd: unknown activation %d", act);
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((d + WAVE - 1) / WAVE, B);
-#define DMN_MS(ACTV, KXV) hipLaunchKernelGGL((mix_sru_fwd_kernel<ACTV, KXV>), grid, dim3(WAVE), lds, s, A, Bt, Pt, \
-                                             Wp, ldw, bias, c0, h, c_last, B, L, K, S, d)
-#define DMN_MSA(KXV)                                                \
-    do {                                                            \
-        if (act == DMN_ACT_TANH) DMN_MS(DMN_ACT_TANH, KXV);         \
-        else if (act == DMN_ACT_RELU) DMN_MS(DMN_ACT_RELU, KXV);    \
-        else DMN_MS(DMN_ACT_IDENTITY, KXV);                         \
+#define DMN_MS(ACTV, KXV, LXV) hipLaunchKernelGGL((mix_sru_fwd_kernel<ACTV, KXV, LXV>), grid, dim3(WAVE), lds, s, A, Bt, Pt, \
+                                                  Wp, ldw, bias, c0, h, c_last, B, L, K, S, d)
+#define DMN_MSA(KXV, LXV)                                                \
+    do {                                                                 \
+        if (act == DMN_ACT_TANH) DMN_MS(DMN_ACT_TANH, KXV, LXV);         \
+        else if (act == DMN_ACT_RELU) DMN_MS(DMN_ACT_RELU, KXV, LXV);    \
+        else DMN_MS(DMN_ACT_IDENTITY, KXV, LXV);                         \
     } while (0)
-    if (K == 10) DMN_MSA(10);
-    else DMN_MSA(0);
+    if (K == 10 && L == 20) DMN_MSA(10, 20);          // the model's default: num_filters 10, 20-word queries
+    else if (K == 10) DMN_MSA(10, 0);
+    else DMN_MSA(0, 0);
 #undef DMN_MSA
 #undef DMN_MS
     return launch_status("dmn_mix_sru_fwd");

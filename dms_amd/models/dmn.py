@@ -32,10 +32,10 @@ from ..sru import SRU
 from .dpn import create_backbone
 
 
-# ops.mix_sru_fwd is issue-bound (~0.8 ms at T = 5120 however few columns), the mix + scan pair is
+# ops.mix_sru_fwd is issue-bound (~0.6 ms at T = 5120 however few columns), the mix + scan pair is
 # HBM-bound and shrinks with the batch: measured cross-over on MI355X (tools/mix_sru_bench.py)
-# near 20 samples of 1005 columns (B=16: 0.68 vs 0.81 ms, B=32: 1.41 vs 0.90, B=64: 2.90 vs 1.27)
-MIX_SCAN_MIN_COLS = 20000
+# near 14 samples of 1005 columns (B=12: 0.57 vs 0.60 ms, B=16: 0.67 vs 0.61, B=32: 1.41 vs 0.62)
+MIX_SCAN_MIN_COLS = 14000
 
 
 def _lenient_load(module, new_state, verbose=False):

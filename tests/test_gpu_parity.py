@@ -326,7 +326,7 @@ def test_hot_path_matches_reference_golden(name):
 
 
 @pytest.mark.parametrize("B,L,K,S,d", [(2, 20, 10, 100, 1005), (1, 5, 3, 12, 7), (3, 4, 1, 7, 70), (2, 6, 10, 9, 64),
-                                       (1, 3, 16, 5, 130), (2, 1, 10, 1, 5)])
+                                       (1, 3, 16, 5, 130), (2, 1, 10, 1, 5), (1, 20, 10, 3, 70), (3, 20, 10, 1, 64)])
 @pytest.mark.parametrize("act", ["tanh", "relu"])
 def test_mix_fused_into_layer0_scan_is_bit_identical_to_mix_then_scan(B, L, K, S, d, act):
     """dmn_mix_sru_fwd == dmn_sru_fwd(dmn_mix_bcast_add(...)) bit for bit (h and c_last), with and
