@@ -350,6 +350,29 @@ def test_mix_fused_into_layer0_scan_is_bit_identical_to_mix_then_scan(B, L, K, S
     np.testing.assert_allclose(c.cpu().numpy(), c_o, rtol=1e-4, atol=1e-5)
 
 
+def test_hot_path_with_fused_layer0_at_batch_16_equals_two_kernel_path_and_batch1():
+    """Full dims (d = 1005, 20 words, 10 filters), 16 samples: above MIX_SCAN_MIN_COLS the hot path
+    takes dmn_mix_sru_fwd by itself; it must equal the mix + scan path bit for bit (both scans are
+    un-chunked at this size) and every sample must equal its own batch-1 forward (reference
+    semantics, dmn.py:142)."""
+    net, vis, lang, g, cfg, _ = _product_base("base_full_320_lowres")
+    import dms_amd.models.dmn as dmn_mod
+    B = 16
+    assert B * net.mrnn.rnn_lst[0].n_out >= dmn_mod.MIX_SCAN_MIN_COLS
+    gen = torch.Generator().manual_seed(3)
+    visb = torch.cat([vis] + [torch.rand(vis.shape, generator=gen) for _ in range(B - 1)]).to(DEV)
+    langb = torch.cat([lang] + [torch.randint(0, int(g["dict_size"]), lang.shape, generator=gen)
+                                for _ in range(B - 1)]).to(DEV)
+    with torch.no_grad():
+        fused = net.hot_path(visb, langb)
+        net.fuse_mix_scan = False
+        pair = net.hot_path(visb, langb)
+        one = net.hot_path(visb[5:6], langb[5:6])
+    assert torch.equal(fused, pair)
+    assert rel_err(fused[:1].cpu(), g["out"]) < 1e-4
+    assert rel_err(fused[5:6], one) < 1e-5
+
+
 def test_folded_layer0_projection_equals_unfused_path():
     """comb_conv folded into the mSRU layer-0 projection (inference) vs the unfused path."""
     net, vis, lang, g, cfg, _ = _product_base("base_full_320_lowres")
