@@ -12,9 +12,14 @@ batch of (image, query) pairs is sharded, no data-path collective ("weak" scalin
 GPU, so N = 8 is configs[2]'s 256).  value = total queries / max-over-ranks wall time.
 
 The same JSON line carries
-  roofline     : the dominant hand-written kernel (the mSRU scan), algorithmic bytes per
-                 launch / average launch duration measured live with HIP events on the
-                 launch stream during the timed steps, vs the 8 TB/s HBM peak;
+  roofline     : the mSRU scan named by the metric -- the longest HBM-bound scan launch of the
+                 step (layer 1, k = 3, T = 5120; layer 0's input is built inside its scan at this
+                 batch size and no longer streamed): algorithmic bytes per launch / average
+                 launch duration measured live with HIP events on the launch stream during the
+                 timed steps, vs the 8 TB/s HBM peak; `hip_kernels` lists every entry point the
+                 same way (plus TFLOP/s for the ones that are issue-bound, not HBM-bound);
+  gemm_table_entries : shapes served from the recorded rocBLAS/hipBLASLt solution table
+                 (dms_amd/tuning/, look-up only; --no-gemm-table to measure without it);
   cpu_baseline : the CPU oracle (oracle/: plain-C scan + pure-torch reference-shaped glue +
                  torch-CPU DPN92) on a bounded sample of the same workload (a few batch-1
                  queries) on this box's host cores -- rank 0, N = 1 only.
