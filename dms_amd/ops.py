@@ -63,14 +63,14 @@ def gemm_backend():
         torch.backends.cuda.preferred_blas_library(prev)
 
 
-GEMM_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning", "gemm_mi355x_b32_512px.csv")
+GEMM_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning", "gemm_mi355x_512px.csv")
 
 
 def use_gemm_table(path=None):
     """Opt in to a recorded per-shape solution table for the library GEMMs (PyTorch TunableOp in
     look-up mode: no tuning at run time).  The table shipped in dms_amd/tuning/ was searched on
-    one MI355X over all rocBLAS + hipBLASLt fp32 solutions for every GEMM shape of the B=32 /
-    512 px inference step (tools/tune_gemms.py); shapes it does not hold keep the library's own
+    one MI355X over all rocBLAS + hipBLASLt fp32 solutions for every GEMM shape of the B=32 and
+    the B=1 512 px inference step (tools/tune_gemms.py); shapes it does not hold keep the library's own
     choice.  TunableOp ignores the file unless its validator lines (torch, HIP, rocBLAS,
     hipBLASLt versions, gfx arch) match the running stack.  Process-global.  Returns the number
     of entries loaded (0: file missing or rejected)."""
