@@ -385,6 +385,9 @@ def main():
     ap.add_argument("--workload", default="dmn512", choices=["dmn512", "msru_stress", "train320"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=25)
+    ap.add_argument("--no-head-link", action="store_true",
+                    help="A/B switch: compact pyramid taps and the two-GEMM head levels instead of the "
+                         "backbone writing each tap into the head's [x | feat] buffer")
     ap.add_argument("--no-gemm-table", action="store_true",
                     help="do not load the recorded per-shape BLAS solution table (dms_amd/tuning/)")
     args = ap.parse_args()
@@ -444,6 +447,8 @@ def main():
     from dms_amd import ops as dmn_ops
     gemm_table_entries = 0 if args.no_gemm_table else dmn_ops.use_gemm_table()
     net = build_model(device)
+    if args.no_head_link:
+        net.langvis.base.tap_prefix = None
     B = args.batch
     g = torch.Generator(device=device).manual_seed(SEED + rank)
     img = torch.randn((B, 3, 512, 512), device=device, generator=g)

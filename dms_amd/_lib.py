@@ -15,6 +15,7 @@ ABI_VERSION = 1
 _p = ctypes.c_void_p
 _i = ctypes.c_int
 _f = ctypes.c_float
+_ll = ctypes.c_longlong
 
 # name -> argtypes, mirrors include/dmn_hip.h one to one
 SIGNATURES = {
@@ -35,15 +36,15 @@ SIGNATURES = {
     "dmn_wino_cat_upsample2x_transform": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "dmn_wino_output_transform": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
     "dmn_head_final": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
-    "dmn_tap_upsample_gather": [_p, _p, _p, _i, _i, _i, _i, _p],
+    "dmn_tap_upsample_gather": [_p, _p, _p, _i, _i, _i, _i, _ll, _p],
     "dmn_tap_project": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
     "dmn_threshold_iou": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
     "dmn_gconv3x3_bn_relu": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "dmn_bn_relu": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
-    "dmn_bn_relu_s2": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "dmn_bn_relu_s2": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _ll, _p],
     "dmn_bn_relu_maxpool": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "dmn_channel_dot": [_p, _p, _p, _p, _i, _i, _i, _p],
-    "dmn_dpn_stage_pass": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "dmn_dpn_stage_pass": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _ll, _p],
     "dmn_dpn_merge": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
 }
 

@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(256)
 dpn_stage_pass_kernel(float *__restrict__ buf, float *__restrict__ act, float *__restrict__ out,
                       const float *__restrict__ mean, const float *__restrict__ scale,
                       const float *__restrict__ bias, long long total, int rows, int c1c, int inc,
-                      int Co, int HWv)
+                      int Co, int HWv, long long out_bsv)
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
@@ -128,7 +128,7 @@ dpn_stage_pass_kernel(float *__restrict__ buf, float *__restrict__ act, float *_
             r.z = fmaxf(__builtin_fmaf(v.z - m, s, b), 0.0f);
             r.w = fmaxf(__builtin_fmaf(v.w - m, s, b), 0.0f);
             reinterpret_cast<float4 *>(act)[i] = r;
-            if (out) reinterpret_cast<float4 *>(out)[i] = v;
+            if (out) reinterpret_cast<float4 *>(out)[n * out_bsv + (long long)c * HWv + hw] = v;
         } else {
             const float v = buf[src];
             if (fresh) {
@@ -136,7 +136,7 @@ dpn_stage_pass_kernel(float *__restrict__ buf, float *__restrict__ act, float *_
                 buf[src] = 0.0f;
             }
             act[i] = fmaxf(__builtin_fmaf(v - m, s, b), 0.0f);
-            if (out) out[i] = v;
+            if (out) out[n * out_bsv + (long long)c * HWv + hw] = v;
         }
     }
 }
@@ -146,7 +146,7 @@ dpn_stage_pass_kernel(float *__restrict__ buf, float *__restrict__ act, float *_
 __global__ void __launch_bounds__(256)
 bn_relu_s2_kernel(const float *__restrict__ x, const float *__restrict__ mean,
                   const float *__restrict__ scale, const float *__restrict__ bias,
-                  float *__restrict__ y, long long total, int C, int Ho, int Wo2, int W)
+                  float *__restrict__ y, long long total, int C, int Ho, int Wo2, int W, long long x_bs)
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
@@ -156,7 +156,8 @@ bn_relu_s2_kernel(const float *__restrict__ x, const float *__restrict__ mean,
         const long long pl = t / Ho;                               // n * C + c
         const int c = (int)(pl % C);
         const float m = mean[c], s = scale[c], b = bias[c];
-        const float4 v = *reinterpret_cast<const float4 *>(x + (pl * 2 * Ho + 2 * oy) * W + 4 * xo);
+        const long long n = pl / C;
+        const float4 v = *reinterpret_cast<const float4 *>(x + n * x_bs + ((long long)c * 2 * Ho + 2 * oy) * W + 4 * xo);
         float2 o;
         o.x = fmaxf(__builtin_fmaf(v.x - m, s, b), 0.0f);
         o.y = fmaxf(__builtin_fmaf(v.z - m, s, b), 0.0f);
@@ -293,31 +294,37 @@ extern "C" int dmn_dpn_merge(const float *base, const float *yv, float *out, flo
 
 extern "C" int dmn_dpn_stage_pass(float *buf, float *act, float *out,
                                   const float *mean, const float *scale, const float *bias,
-                                  int N, int rows, int c1c, int inc, int Co, int HW, void *stream)
+                                  int N, int rows, int c1c, int inc, int Co, int HW, long long out_bs,
+                                  void *stream)
 {
+    if (out && out_bs < (long long)Co * HW)
+        return fail(-4, "dmn_dpn_stage_pass: out batch stride %lld < Co*HW", out_bs);
     if (!buf || !act || !mean || !scale || !bias) return fail(-1, "dmn_dpn_stage_pass: NULL pointer");
     if (N <= 0 || HW <= 0 || c1c <= 0 || inc <= 0 || Co < c1c + 3 * inc || (Co - c1c - 2 * inc) % inc ||
         rows < Co + inc)
         return fail(-4, "dmn_dpn_stage_pass: bad sizes N=%d rows=%d c1c=%d inc=%d Co=%d HW=%d", N, rows, c1c, inc, Co, HW);
-    const bool vec = HW % 4 == 0 && !(((uintptr_t)buf | (uintptr_t)act | (uintptr_t)out) & 15);
+    const bool vec = HW % 4 == 0 && out_bs % 4 == 0 && !(((uintptr_t)buf | (uintptr_t)act | (uintptr_t)out) & 15);
     const int hwv = vec ? HW / 4 : HW;
+    const long long obs = vec ? out_bs / 4 : out_bs;
     const long long total = (long long)N * Co * hwv;
     hipStream_t s = (hipStream_t)stream;
-    if (vec) hipLaunchKernelGGL(dpn_stage_pass_kernel<4>, dim3(grid_for(total)), dim3(256), 0, s, buf, act, out, mean, scale, bias, total, rows, c1c, inc, Co, hwv);
-    else hipLaunchKernelGGL(dpn_stage_pass_kernel<1>, dim3(grid_for(total)), dim3(256), 0, s, buf, act, out, mean, scale, bias, total, rows, c1c, inc, Co, hwv);
+    if (vec) hipLaunchKernelGGL(dpn_stage_pass_kernel<4>, dim3(grid_for(total)), dim3(256), 0, s, buf, act, out, mean, scale, bias, total, rows, c1c, inc, Co, hwv, obs);
+    else hipLaunchKernelGGL(dpn_stage_pass_kernel<1>, dim3(grid_for(total)), dim3(256), 0, s, buf, act, out, mean, scale, bias, total, rows, c1c, inc, Co, hwv, obs);
     return launch_status("dmn_dpn_stage_pass");
 }
 
 extern "C" int dmn_bn_relu_s2(const float *x, const float *mean, const float *scale, const float *bias,
-                              float *y, int N, int C, int H, int W, void *stream)
+                              float *y, int N, int C, int H, int W, long long x_bs, void *stream)
 {
+    if (x_bs < (long long)C * H * W || x_bs % 4)
+        return fail(-4, "dmn_bn_relu_s2: x batch stride %lld must be >= C*H*W and a multiple of 4", x_bs);
     if (!x || !mean || !scale || !bias || !y) return fail(-1, "dmn_bn_relu_s2: NULL pointer");
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || H % 2 || W % 4)
         return fail(-4, "dmn_bn_relu_s2: needs H %% 2 == 0 and W %% 4 == 0 (N=%d C=%d H=%d W=%d)", N, C, H, W);
     if (((uintptr_t)x & 15) || ((uintptr_t)y & 7)) return fail(-7, "dmn_bn_relu_s2: x must be 16-byte, y 8-byte aligned");
     const long long total = (long long)N * C * (H / 2) * (W / 4);
     hipLaunchKernelGGL(bn_relu_s2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                       x, mean, scale, bias, y, total, C, H / 2, W / 4, W);
+                       x, mean, scale, bias, y, total, C, H / 2, W / 4, W, x_bs);
     return launch_status("dmn_bn_relu_s2");
 }
 

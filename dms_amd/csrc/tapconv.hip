@@ -70,7 +70,7 @@ __device__ __forceinline__ void tap_hrow(const float *__restrict__ zplane, long 
 template <int CPL>
 __global__ void __launch_bounds__(256)
 tap_gather_kernel(const float *__restrict__ Z, const float *__restrict__ bias, float *__restrict__ out,
-                  int B, int Cout, int H, int W, int RB)
+                  int B, int Cout, int H, int W, int RB, long long out_bs)
 {
     const int Wl = (W + CPL - 1) / CPL;
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -85,7 +85,7 @@ tap_gather_kernel(const float *__restrict__ Z, const float *__restrict__ bias, f
     const long long tapstride = (long long)Cout * HW;
     const float *zplane = Z + ((long long)b * 9 * Cout + co) * HW;
     const float bv = bias ? bias[co] : 0.0f;
-    float *oplane = out + (long long)plane * 4 * HW;
+    float *oplane = out + (long long)b * out_bs + (long long)co * 4 * HW;
     const int W2 = 2 * W;
 
     TapRow<CPL> Rm, Rc, Rp;
@@ -168,8 +168,10 @@ tap_project_kernel(const float *__restrict__ x, const float *__restrict__ feat,
 using namespace dmn;
 
 extern "C" int dmn_tap_upsample_gather(const float *Z, const float *bias, float *out,
-                                       int B, int Cout, int H, int W, void *stream)
+                                       int B, int Cout, int H, int W, long long out_bs, void *stream)
 {
+    if (out_bs < (long long)Cout * 4 * H * W || out_bs % 4)
+        return fail(-4, "dmn_tap_upsample_gather: out batch stride %lld must be >= Cout*4*H*W and a multiple of 4", out_bs);
     if (!Z || !out) return fail(-1, "dmn_tap_upsample_gather: NULL pointer");
     if (B <= 0 || Cout <= 0 || H <= 0 || W <= 0)
         return fail(-4, "dmn_tap_upsample_gather: bad sizes B=%d Cout=%d H=%d W=%d", B, Cout, H, W);
@@ -190,8 +192,8 @@ extern "C" int dmn_tap_upsample_gather(const float *Z, const float *bias, float 
     if (chunks > 65535) return fail(-5, "dmn_tap_upsample_gather: H=%d too large", H);
     dim3 grid((unsigned)blocks, chunks);
     hipStream_t s = (hipStream_t)stream;
-    if (two) hipLaunchKernelGGL(tap_gather_kernel<2>, grid, dim3(256), 0, s, Z, bias, out, B, Cout, H, W, RB);
-    else hipLaunchKernelGGL(tap_gather_kernel<1>, grid, dim3(256), 0, s, Z, bias, out, B, Cout, H, W, RB);
+    if (two) hipLaunchKernelGGL(tap_gather_kernel<2>, grid, dim3(256), 0, s, Z, bias, out, B, Cout, H, W, RB, out_bs);
+    else hipLaunchKernelGGL(tap_gather_kernel<1>, grid, dim3(256), 0, s, Z, bias, out, B, Cout, H, W, RB, out_bs);
     return launch_status("dmn_tap_upsample_gather");
 }
 

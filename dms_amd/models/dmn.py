@@ -250,6 +250,35 @@ class UpsamplingModule(nn.Module):
                 and conv.kernel_size == (3, 3) and conv.padding == (1, 1) and conv.stride == (1, 1)
                 and conv.dilation == (1, 1) and conv.groups == 1)
 
+    @staticmethod
+    def _concat_base_for(f, B, Cx, H, W):
+        """The (B, Cx + Cf, H, W) buffer whose last Cf channels are the view `f`, or None."""
+        base = getattr(f, "_dmn_base", None)
+        if base is None or not torch.is_tensor(base) or base.dim() != 4 or not base.is_contiguous():
+            return None
+        if f.dim() != 4 or tuple(f.shape[2:]) != (H, W) or f.shape[0] != B:
+            return None
+        Cf = f.shape[1]
+        if tuple(base.shape) != (B, Cx + Cf, H, W) or f.stride() != (base.stride(0), H * W, W, 1):
+            return None
+        if f.storage_offset() != base.storage_offset() + Cx * H * W or not f.is_cuda or f.dtype != torch.float32:
+            return None
+        return base
+
+    def _concat_base(self, x, f):
+        return self._concat_base_for(f, x.shape[0], x.shape[1], x.shape[2], x.shape[3])
+
+    def _tap_weight_full(self, conv):
+        """Wt (9*Cout, Cx+Cf) of a level's conv weight in tap-major row order, cached per weight version."""
+        w = conv.weight
+        key = (w._version, w.data_ptr())
+        cached = conv.__dict__.get("_dmn_tap_full")
+        if cached is None or cached[0] != key:
+            with torch.no_grad():
+                cached = (key, ops.tap_weight(w.detach()))
+            conv.__dict__["_dmn_tap_full"] = cached
+        return cached[1]
+
     def _tap_weights(self, conv, cx):
         """(Wt[:, :cx], Wt[:, cx:]) of a level's conv weight in tap-major row order, cached per
         weight version."""
@@ -306,10 +335,27 @@ class UpsamplingModule(nn.Module):
                 return ops.head_final(x.contiguous(), f.contiguous(), weff, b_eff)
             m = 0 if self._tap_ok(conv, x) else self._winograd_tile(conv, x)
             if self._tap_ok(conv, x):
-                wt_x, wt_f = self._tap_weights(conv, x.shape[1])
-                Z = ops.tap_gemm(x.contiguous(), f.contiguous(), wt_x, wt_f)
-                x = ops.tap_upsample_gather(Z, conv.bias)
                 rest = list(level)[2:]
+                base = self._concat_base(x, f)
+                if base is not None:
+                    # the backbone wrote this tap behind room for x: [x | feat] is ONE tensor and the
+                    # level ONE GEMM with K = Cx + Cf (no second GEMM re-reading Z with beta = 1)
+                    B, Cx, H, W = x.shape
+                    if x.data_ptr() != base.data_ptr():
+                        base[:, :Cx].copy_(x)
+                    Z = ops.tuned_matmul(self._tap_weight_full(conv), base.view(B, base.shape[1], H * W))
+                    Z = Z.view(B, 9, conv.out_channels, H, W)
+                else:
+                    wt_x, wt_f = self._tap_weights(conv, x.shape[1])
+                    Z = ops.tap_gemm(x.contiguous(), f.contiguous(), wt_x, wt_f)
+                # write straight into the next level's [x | feat] buffer when there is one
+                dest = None
+                if not rest and i >= 1 and level is not self.convs[-1]:
+                    nb_ = self._concat_base_for(features[i - 1], x.shape[0], conv.out_channels,
+                                                2 * x.shape[2], 2 * x.shape[3])
+                    if nb_ is not None:
+                        dest = nb_[:, :conv.out_channels]
+                x = ops.tap_upsample_gather(Z, conv.bias, out=dest)
             elif m:
                 B, _, H, W = x.shape
                 V = ops.wino_cat_upsample2x_transform(x.contiguous(), f.contiguous(), m)
@@ -410,8 +456,26 @@ class DMN(nn.Module):
             self.upsample = UpsamplingModule(
                 hid_mixed_size, mode=upsampling_mode, ker_size=upsampling_size,
                 amplification=upsampling_amplification)
+            self._link_head_buffers(hid_mixed_size)
         if dmn_freeze:
             self.langvis.eval()
+
+    def _link_head_buffers(self, hid_mixed_size):
+        """Inference: let the backbone write each pyramid tap behind room for the head level's own
+        input channels (DPN.tap_prefix), so that cat([x, feat]) (dmn.py:337) exists without a copy:
+        level i reads features[4 - i]; its x has hid_mixed_size (i = 0) or the previous level's
+        out_channels."""
+        base = self.langvis.base
+        taps = getattr(base, "taps", None)
+        if not taps or len(taps) != 4 or not hasattr(base, "tap_prefix"):
+            return
+        prefix, cx = {}, int(hid_mixed_size)
+        for i, level in enumerate(self.upsample.convs):
+            k = 4 - i                                           # index into features
+            if k >= 1:
+                prefix[taps[k - 1]] = cx
+            cx = level[1].out_channels
+        base.tap_prefix = prefix
 
     def forward(self, vis, lang):
         if self.dmn_freeze:

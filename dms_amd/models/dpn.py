@@ -229,6 +229,11 @@ class DPN(nn.Module):
         self.fusable = not b
         self.fuse_glue = True          # set False to force the plain torch path
         self.stage_inplace = True      # fused path: one in-place buffer per stage (False: dpn_merge per block)
+        # fused path: {tap name: p}: that pyramid tap is written as the LAST channels of a
+        # (N, p + C, H, W) buffer (returned as the view buf[:, p:]) so that a consumer can put p
+        # channels of its own in front and read [its | tap] as one tensor (the high-res head's
+        # per-level GEMM; set by DMN).  None / missing name: compact tap.
+        self.tap_prefix = None
 
     def _forward_fused(self, x):
         children = list(self.features.named_children())
@@ -253,6 +258,7 @@ class DPN(nn.Module):
                 X, act = self._run_stage(blocks[i:j], X, act, nxt)
                 feats.append(X)
             else:
+                X = X.contiguous()                             # (a prefixed tap is a batch-strided view)
                 for k in range(i, j):
                     name, block = blocks[k]
                     nb = blocks[k + 1][1].c1x1_a.bn if k + 1 < len(blocks) else final.bn
@@ -286,6 +292,8 @@ class DPN(nn.Module):
         the next pre-activation; the residual and the old dense channels are never copied."""
         first = stage[0][1]
         c1c, inc, nb = first.c1c, first.inc, len(stage)
+        if first.kind != "down" and not X.is_contiguous():
+            X = X.contiguous()                                 # only bn_relu_s2 reads batch-strided taps
         if act is None:
             act = _bn_relu(first.c1x1_a.bn, X)
         if first.kind == "down":
@@ -302,14 +310,20 @@ class DPN(nn.Module):
         ops.tuned_matmul(_proj_weight(w.conv, c1c), pin.view(N, Cin, Hs * Ws), out=buf3[:, :2 * inc + c1c])
         res_slot = buf3[:, 2 * inc:3 * inc + c1c]
         out = None
+        prefix = (self.tap_prefix or {}).get(stage[-1][0], 0)
+        if prefix:
+            Co_last = c1c + 2 * inc + nb * inc
+            whole = torch.empty((N, prefix + Co_last, Hs, Ws), device=X.device, dtype=torch.float32)
+            out = whole[:, prefix:]
+            out._dmn_base = whole          # (tensor._base is not available under inference_mode)
         for m, (name, block) in enumerate(stage, 1):
             y = block._y_path(act)
             wc = block.c1x1_c.conv.weight
             ops.tuned_matmul(wc.view(wc.shape[0], wc.shape[1]), y.view(N, y.shape[1], Hs * Ws), acc=res_slot)
             bn = stage[m][1].c1x1_a.bn if m < nb else next_bn
-            act, out = ops.dpn_stage_pass(buf, c1c, inc, c1c + 2 * inc + m * inc, _bn_consts(bn),
-                                          want_out=(m == nb))
-        return out, act
+            act, tap = ops.dpn_stage_pass(buf, c1c, inc, c1c + 2 * inc + m * inc, _bn_consts(bn),
+                                          want_out=(m == nb), out=out if m == nb else None)
+        return tap, act
 
     def forward(self, x):
         if (self.fuse_glue and self.fusable and not self.training

@@ -38,6 +38,18 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+def _chk_batch_strided(name, t, shape=None):
+    """Like _chk, but the batch dimension may be strided (a channel-slice view of a larger
+    (N, C', H, W) buffer): every sample must be contiguous.  Returns the batch stride in floats."""
+    if not t.is_cuda or t.dtype != torch.float32:
+        raise RuntimeError("dms_amd.%s: expected a float32 ROCm tensor" % name)
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise RuntimeError("dms_amd.%s: expected shape %s, got %s" % (name, tuple(shape), tuple(t.shape)))
+    if not t[0].is_contiguous() or t.stride(0) < t[0].numel():
+        raise RuntimeError("dms_amd.%s: every sample must be contiguous" % name)
+    return int(t.stride(0))
+
+
 _BLAS_NAMES = {"rocblas": "cublas", "hipblaslt": "cublaslt"}
 
 
@@ -505,15 +517,18 @@ def tap_gemm(x, feat, wt_x, wt_f):
     return Z.view(B, 9, R // 9, H, W)
 
 
-def tap_upsample_gather(Z, bias):
+def tap_upsample_gather(Z, bias, out=None):
     """out (B, Cout, 2H, 2W) = bias + sum over the 9 taps of shift_tap(upsample2x(Z[:, tap]))
-    (zero outside the high-res image); Z (B, 9, Cout, H, W)."""
+    (zero outside the high-res image); Z (B, 9, Cout, H, W).  `out` may be given: e.g. the first
+    Cout channels of the next level's [x | feat] buffer (batch-strided view)."""
     B, nine, Cout, H, W = Z.shape
     _chk("tap_upsample_gather", Z, (B, 9, Cout, H, W))
     _chk("tap_upsample_gather", bias, (Cout,) if bias is not None else None)
     with torch.cuda.device(Z.device):
-        out = torch.empty((B, Cout, 2 * H, 2 * W), device=Z.device, dtype=torch.float32)
-        _lib.call("dmn_tap_upsample_gather", _ptr(Z), _ptr(bias), _ptr(out), B, Cout, H, W, _stream())
+        if out is None:
+            out = torch.empty((B, Cout, 2 * H, 2 * W), device=Z.device, dtype=torch.float32)
+        bs = _chk_batch_strided("tap_upsample_gather", out, (B, Cout, 2 * H, 2 * W))
+        _lib.call("dmn_tap_upsample_gather", _ptr(Z), _ptr(bias), _ptr(out), B, Cout, H, W, bs, _stream())
     return out
 
 
@@ -555,12 +570,12 @@ def bn_relu(x, mean, scale, bias):
 def bn_relu_s2(x, mean, scale, bias):
     """relu(bn(x))[:, :, ::2, ::2] for x (N, C, H, W) with even H and W % 4 == 0."""
     N, C, H, W = x.shape
-    _chk("bn_relu_s2", x)
+    bs = _chk_batch_strided("bn_relu_s2", x)                  # x may be a channel slice of a larger buffer
     _chk_bn("bn_relu_s2", (mean, scale, bias), C)
     with torch.cuda.device(x.device):
         y = torch.empty((N, C, H // 2, W // 2), device=x.device, dtype=torch.float32)
         _lib.call("dmn_bn_relu_s2", _ptr(x), _ptr(mean), _ptr(scale), _ptr(bias), _ptr(y), N, C, H, W,
-                  _stream())
+                  bs, _stream())
     return y
 
 
@@ -619,19 +634,22 @@ def gconv3x3_bn_relu(x, weight_t, groups, bn_in=None, bn_out=None, stride=1):
     return y
 
 
-def dpn_stage_pass(buf, c1c, inc, Co, bn, want_out=False):
+def dpn_stage_pass(buf, c1c, inc, Co, bn, want_out=False, out=None):
     """In-place DPN stage buffer buf (N, rows, H, W) = [dense0 | res | slot | o2_1 ..] after the
     beta = 1 GEMM onto [res | slot]: returns (act, out) with act (N, Co, H, W) = relu(bn(X)) in the
     reference channel order and out = X itself when want_out (else None); moves the slot's
-    channels to their final rows and zeroes the slot (see dmn_dpn_stage_pass)."""
+    channels to their final rows and zeroes the slot (see dmn_dpn_stage_pass).  `out` may be given
+    (a batch-strided (N, Co, H, W) view, e.g. the feat channels of the head's [x | feat] buffer)."""
     N, rows, H, W = buf.shape
     _chk("dpn_stage_pass", buf)
     _chk_bn("dpn_stage_pass", bn, Co)
     with torch.cuda.device(buf.device):
         act = torch.empty((N, Co, H, W), device=buf.device, dtype=torch.float32)
-        out = torch.empty_like(act) if want_out else None
+        if out is None and want_out:
+            out = torch.empty_like(act)
+        bs = _chk_batch_strided("dpn_stage_pass", out, (N, Co, H, W)) if out is not None else Co * H * W
         _lib.call("dmn_dpn_stage_pass", _ptr(buf), _ptr(act), _ptr(out), _ptr(bn[0]), _ptr(bn[1]),
-                  _ptr(bn[2]), N, rows, int(c1c), int(inc), int(Co), H * W, _stream())
+                  _ptr(bn[2]), N, rows, int(c1c), int(inc), int(Co), H * W, bs, _stream())
     return act, out
 
 

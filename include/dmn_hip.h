@@ -217,12 +217,15 @@ int dmn_head_final(const float *x, const float *feat, const float *weff, const f
  *   out[b, o, y, x] = bias[o] + sum_{ky,kx} up2(Z[b, ky*3+kx, o])[y + ky - 1, x + kx - 1]
  *   with up2 = bilinear x2 (align_corners=False) and zero outside the (2H, 2W) image.
  *   Z (B, 9, Cout, H, W) -> out (B, Cout, 2H, 2W); bias (Cout) or NULL.
+ *   out_bs: floats between consecutive samples of out (Cout*4*H*W when out is compact; larger when
+ *   out is the first Cout channels of the NEXT level's [x | feat] buffer, so that level's GEMM reads
+ *   one operand with K = Cx + Cf and nobody copies).
  * dmn_tap_project: the projection itself for the 9-row case Cout == 1 (last level composed with
  * out_layer, see dmn_head_final), where a GEMM with 9 rows is a poor fit for a BLAS library:
  *   Z (B, 9, HW) = w (9, Cx+Cf) . cat(x, feat)[b];  x (B, Cx, HW), feat (B, Cf, HW) (either may be empty).
  */
 int dmn_tap_upsample_gather(const float *Z, const float *bias, float *out,
-                            int B, int Cout, int H, int W, void *stream);
+                            int B, int Cout, int H, int W, long long out_bs, void *stream);
 int dmn_tap_project(const float *x, const float *feat, const float *w, float *Z,
                     int B, int Cx, int Cf, int HW, void *stream);
 
@@ -277,9 +280,9 @@ int dmn_bn_relu(const float *x, const float *mean, const float *scale, const flo
                 float *y, int N, int C, int HW, void *stream);
 /* dmn_bn_relu_s2: y (N, C, H/2, W/2) = relu(bn(x))[:, :, ::2, ::2] -- the pre-activation of the
  * stride-2 1x1 projection `c1x1_w_s2` (dpn_model.py:208-213), which reads a quarter of x only.
- * H % 2 == 0, W % 4 == 0. */
+ * H % 2 == 0, W % 4 == 0.  x_bs: floats between consecutive samples of x (C*H*W when compact). */
 int dmn_bn_relu_s2(const float *x, const float *mean, const float *scale, const float *bias,
-                   float *y, int N, int C, int H, int W, void *stream);
+                   float *y, int N, int C, int H, int W, long long x_bs, void *stream);
 /* dmn_bn_relu_maxpool: y (N, C, (H-1)/2+1, W/2) = MaxPool2d(3, stride 2, padding 1)(relu(bn(x))) -- the
  * stem's bn + act + pool (InputBlock, dpn_model.py:186-197) in one pass over the raw conv output
  * (which stays in memory as pyramid level 0).  W % 4 == 0. */
@@ -297,11 +300,13 @@ int dmn_dpn_merge(const float *base, const float *yv, float *out, float *act,
  * GEMM epilogue.  This pass writes act (N, Co, HW) = relu(bn(X)) with X in the reference's channel
  * order [res | dense0 | o2_1 .. | slot] (dpn_model.py:246,267-269) for the (mean, scale, bias) of the
  * next consumer, moves the slot's channels to their final rows [Co .. Co + inc), zeroes
- * the slot, and writes X itself to out (N, Co, HW) when out != NULL (pyramid taps).
+ * the slot, and writes X itself to out (N, Co, HW) when out != NULL (pyramid taps); out_bs = floats
+ * between consecutive samples of out (Co*HW when compact; larger when the tap is written straight
+ * into the head's [x | feat] buffer).
  */
 int dmn_dpn_stage_pass(float *buf, float *act, float *out,
                        const float *mean, const float *scale, const float *bias,
-                       int N, int rows, int c1c, int inc, int Co, int HW, void *stream);
+                       int N, int rows, int c1c, int inc, int Co, int HW, long long out_bs, void *stream);
 
 #ifdef __cplusplus
 }

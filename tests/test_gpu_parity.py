@@ -921,3 +921,37 @@ def test_recorded_gemm_table_lookup_keeps_results_and_leaves_the_table_alone():
         tunable.enable(False)
     with open(ops.GEMM_TABLE, "rb") as f:
         assert hashlib.md5(f.read()).hexdigest() == before
+
+
+def test_head_reads_backbone_taps_in_place_as_one_concat_operand():
+    """DMN links the backbone's pyramid taps to the head: each tap is written behind room for the
+    level's own input (DPN.tap_prefix), the level runs ONE GEMM over [x | feat] and the gather
+    writes into the next level's buffer.  Must equal the compact-tap / two-GEMM path."""
+    net = dms_amd.DMN(100, num_filters=10, lang_layers=3, mix_we=True, pretrained=False,
+                      high_res=True, upsampling_mode="bilinear", upsampling_amplification=32)
+    torch.nn.Module.load_state_dict(net, det_fill_state(net.state_dict()))
+    net = net.to(DEV).eval()
+    base = net.langvis.base
+    assert base.tap_prefix == {"conv5_3": 1005, "conv4_20": 512, "conv3_4": 256, "conv2_3": 128}
+    words = det_ints((2, 6), 152, 100).to(DEV)
+    # 128 x 192: every stage takes the in-place path; 128 x 96: the last one falls back (6-wide map),
+    # so its tap is compact and that level runs the two-GEMM path next to linked ones
+    for size, nlinked in (((128, 192), 4), ((128, 96), 3)):
+        img = det_uniform((2, 3) + size, 151, 1.0).to(DEV)
+        with torch.no_grad():
+            _, feats = base(img)
+            for k, (c, p) in enumerate(((336, 128), (704, 256), (1552, 512), (2688, 1005)), 1):
+                f = feats[k]
+                assert f.shape[1] == c
+                if k <= nlinked:
+                    assert f._dmn_base.shape[1] == p + c and not f.is_contiguous()
+                else:
+                    assert f.is_contiguous()
+            linked = net(img, words)
+            keep, base.tap_prefix = base.tap_prefix, None
+            _, feats_c = base(img)
+            compact = net(img, words)
+            base.tap_prefix = keep
+        assert all(a.is_contiguous() for a in feats_c)
+        assert all(torch.equal(a, b) for a, b in zip(feats, feats_c))
+        assert linked.shape == (2, 1) + size and rel_err(linked, compact) < 1e-5
