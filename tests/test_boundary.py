@@ -126,3 +126,37 @@ def test_sru_module_surface():
     assert float(w.abs().max()) <= (3.0 / 6) ** 0.5 + 1e-6 and float(rnn.rnn_lst[0].bias.abs().sum()) == 0
     with pytest.raises(NotImplementedError):
         dms_amd.SRU(4, 4, bidirectional=True)
+
+
+def test_tap_decomposition_algebra_on_cpu():
+    """The identity behind the head's tap GEMM (dms_amd/csrc/tapconv.hip), checked in plain torch:
+    conv3x3_pad1(up2(X)) == sum over taps of shift_tap(up2(W_tap . X)) with zero padding at the
+    HIGH-res border, W_tap rows laid out as ops.tap_weight does."""
+    import torch.nn.functional as F
+    from dms_amd import ops
+    torch.manual_seed(0)
+    B, C, Co, H, W = 2, 5, 3, 4, 6
+    x = torch.randn(B, C, H, W, dtype=torch.float64)
+    w = torch.randn(Co, C, 3, 3, dtype=torch.float64)
+    want = F.conv2d(F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False), w, padding=1)
+    wt = ops.tap_weight(w)                                       # (9*Co, C), row = tap*Co + o
+    assert wt.shape == (9 * Co, C)
+    Z = torch.einsum("rc,bchw->brhw", wt, x).view(B, 9, Co, H, W)
+    got = torch.zeros_like(want)
+    for ky in range(3):
+        for kx in range(3):
+            up = F.interpolate(Z[:, ky * 3 + kx], scale_factor=2, mode="bilinear", align_corners=False)
+            up = F.pad(up, (1, 1, 1, 1))                          # zero outside the high-res image
+            got += up[:, :, ky:ky + 2 * H, kx:kx + 2 * W]
+    assert float((got - want).abs().max()) < 1e-12
+
+
+def test_dmn_links_backbone_taps_to_head_levels():
+    """DMN tells the backbone how many channels each head level puts in front of its pyramid tap
+    (cat([x, features[i]]) of dmn.py:337 without a copy): level i reads features[4 - i]."""
+    import dms_amd
+    net = dms_amd.DMN(50, num_filters=10, lang_layers=3, mix_we=True, pretrained=False, high_res=True,
+                      upsampling_mode="bilinear", upsampling_amplification=32)
+    assert net.langvis.base.tap_prefix == {"conv5_3": 1005, "conv4_20": 512, "conv3_4": 256, "conv2_3": 128}
+    low = dms_amd.DMN(50, num_filters=10, lang_layers=3, mix_we=True, pretrained=False, high_res=False)
+    assert low.langvis.base.tap_prefix is None
