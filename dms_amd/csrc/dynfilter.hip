@@ -40,7 +40,10 @@ dynfilter_fwd_vec(const float *__restrict__ V, const float *__restrict__ F, floa
     const float *Ap = F + (a_ok ? lbk_row(r0 + ar, b, B, K, C) : 0);
     const bool b_ok = (s0 + bc) < S;                 // S % 4 == 0 -> whole float4 in or out
 
-    float acc[4][4] = {};
+    // column pairs ride v_pk_fma_f32 (the filter value is broadcast by op_sel): twice the FMA rate
+    f32x2_t acc2[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc2[i][0] = acc2[i][1] = (f32x2_t){0.0f, 0.0f};
     float4 av = make_float4(0, 0, 0, 0), bv = make_float4(0, 0, 0, 0);
     auto fetch = [&](int c0) {
         av = (a_ok && c0 + ac < C) ? *reinterpret_cast<const float4 *>(Ap + c0 + ac) : make_float4(0, 0, 0, 0);
@@ -57,11 +60,14 @@ dynfilter_fwd_vec(const float *__restrict__ V, const float *__restrict__ F, floa
         for (int kk = 0; kk < BK; ++kk) {
             const float4 a = *reinterpret_cast<const float4 *>(&As[kk][ty * 4]);
             const float4 w = *reinterpret_cast<const float4 *>(&Bs[kk][tx * 4]);
-            const float aa[4] = {a.x, a.y, a.z, a.w}, ww[4] = {w.x, w.y, w.z, w.w};
+            const float aa[4] = {a.x, a.y, a.z, a.w};
+            const f32x2_t w01 = {w.x, w.y}, w23 = {w.z, w.w};
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fmaf(aa[i], ww[j], acc[i][j]);
+            for (int i = 0; i < 4; ++i) {
+                const f32x2_t ai = {aa[i], aa[i]};
+                acc2[i][0] = __builtin_elementwise_fma(ai, w01, acc2[i][0]);
+                acc2[i][1] = __builtin_elementwise_fma(ai, w23, acc2[i][1]);
+            }
         }
         __syncthreads();
     }
@@ -72,7 +78,7 @@ dynfilter_fwd_vec(const float *__restrict__ V, const float *__restrict__ F, floa
             const int r = r0 + ty * 4 + i;
             if (r < R)
                 *reinterpret_cast<float4 *>(P + lbk_row(r, b, B, K, S) + sc) =
-                    make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+                    make_float4(acc2[i][0].x, acc2[i][0].y, acc2[i][1].x, acc2[i][1].y);
         }
     }
 }
