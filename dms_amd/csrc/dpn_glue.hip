@@ -157,7 +157,8 @@ bn_relu_s2_kernel(const float *__restrict__ x, const float *__restrict__ mean,
         const int c = (int)(pl % C);
         const float m = mean[c], s = scale[c], b = bias[c];
         const long long n = pl / C;
-        const float4 v = *reinterpret_cast<const float4 *>(x + n * x_bs + ((long long)c * 2 * Ho + 2 * oy) * W + 4 * xo);
+        const f32x4_t v = __builtin_nontemporal_load(
+            reinterpret_cast<const f32x4_t *>(x + n * x_bs + ((long long)c * 2 * Ho + 2 * oy) * W + 4 * xo));
         float2 o;
         o.x = fmaxf(__builtin_fmaf(v.x - m, s, b), 0.0f);
         o.y = fmaxf(__builtin_fmaf(v.z - m, s, b), 0.0f);
@@ -187,7 +188,7 @@ bn_relu_maxpool_kernel(const float *__restrict__ x, const float *__restrict__ me
         const float m = mean[c], s = scale[c], b = bias[c];
         const float *xp = x + pl * H * W + 4 * l;
         auto hrow = [&](int r, float &h0, float &h1) {
-            const float4 v = *reinterpret_cast<const float4 *>(xp + (long long)r * W);
+            const float4 v = *reinterpret_cast<const float4 *>(xp + (long long)r * W);   // (non-temporal: slower, rows are shared)
             const float left = l > 0 ? fmaxf(__builtin_fmaf(xp[(long long)r * W - 1] - m, s, b), 0.0f) : 0.0f;
             const float a0 = fmaxf(__builtin_fmaf(v.x - m, s, b), 0.0f);
             const float a1 = fmaxf(__builtin_fmaf(v.y - m, s, b), 0.0f);

@@ -142,7 +142,8 @@ tap_project_kernel(const float *__restrict__ x, const float *__restrict__ feat,
         for (int c = 0; c < n; ++c) {
             float v[VEC];
             if (VEC == 4) {
-                const float4 t = *reinterpret_cast<const float4 *>(src + (long long)c * HW);
+                // read once: non-temporal, so the stream does not displace the 9 output rows
+                const f32x4_t t = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(src + (long long)c * HW));
                 v[0] = t.x; v[1] = t.y; v[2] = t.z; v[VEC - 1] = t.w;
             } else {
                 v[0] = src[(long long)c * HW];
