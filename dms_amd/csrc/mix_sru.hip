@@ -6,10 +6,12 @@
 // dmn_mix_bcast_add writes that tensor (16 B per element, 2.6 GB at B=32 / 512 px) and dmn_sru_fwd
 // reads it back once.  Here the scan lane that owns column (b, j) builds its four gate values of a
 // step in registers and consumes them on the spot: U0 is never stored.  What is left in memory
-// traffic is A (read once), the per-word rows Bt (kept per lane in LDS), P (wave-uniform: staged
-// through LDS a pixel ahead, read back as broadcasts) and the h store -- the kernel is bound by one wave's in-order issue (~230 cycles per step:
-// 10 x 4 FMAs on top of the scan's 17 operations), not by HBM, and beats the two-kernel path
-// once there are enough columns to occupy the SIMDs (the caller decides).
+// traffic is A (read once), the per-word rows Bt, P (wave-uniform) and the h store.  The kernel
+// is bound by one wave's in-order issue, not by HBM (generic variant: Bt rows and P staged in
+// LDS, ~380 cycles per step; K = 10 / L = 20 variant: Bt rows in registers, P through
+// v_readlane, ~280 cycles per step = 10 readlane + 22 packed FMA/add + the scan's 17 operations),
+// and beats the two-kernel path once there are enough columns to occupy the SIMDs (the caller
+// decides, see MIX_SCAN_MIN_COLS in dms_amd/models/dmn.py).
 //
 // The arithmetic repeats dmn_mix_bcast_add's and dmn_sru_fwd's operation for operation (same
 // order of the additions and FMAs, same gate formulas), so h is bit-identical to the unfused path.
