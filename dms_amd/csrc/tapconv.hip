@@ -9,8 +9,9 @@
 // (2.25 MACs per high-res output and input channel, the same as Winograd F(4x4,3x3), but exact
 // fp32 products, no input transform and no 2.25x-sized V tensor), and what is left is the
 // HBM-bound gather below: upsample each of the nine Z planes, shift it by its tap offset with
-// zero padding at the HIGH-res border, sum, add the bias.  cat() never happens: the GEMM is
-// split over K into an x part and a feat part by the caller.
+// zero padding at the HIGH-res border, sum, add the bias.  cat() costs nothing either way: inside
+// DMN the backbone writes the tap behind room for x and the previous gather writes x there (out_bs),
+// so [x | feat] is one operand; a stand-alone caller splits the GEMM over K into an x and a feat part.
 //
 // dmn_tap_project is the same projection for the case Cout == 1 (last level composed with
 // out_layer), where a 9-row GEMM would be a poor fit for the BLAS libraries: a lane owns 4
