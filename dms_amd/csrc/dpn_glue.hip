@@ -106,12 +106,15 @@ dpn_stage_pass_kernel(float *__restrict__ buf, float *__restrict__ act, float *_
                       const float *__restrict__ bias, long long total, int rows, int c1c, int inc,
                       int Co, int HWv, long long out_bsv)
 {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int hw = (int)(i % HWv);
-        const long long pl = i / HWv;
-        const int c = (int)(pl % Co);
-        const long long n = pl / Co;
+    // grid: x over the Co*HWv items of one sample (32-bit index math, one item per lane), y = sample
+    const unsigned per = (unsigned)Co * (unsigned)HWv;
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < per) {
+        const long long n = blockIdx.y;
+        const int c = (int)(idx / (unsigned)HWv);
+        const int hw = (int)(idx - (unsigned)c * (unsigned)HWv);
+        const long long i = n * per + idx;
+        (void)total;
         const bool fresh = c >= Co - inc;                               // this block's out2: in the slot
         const int row = c < c1c ? 2 * inc + c : (c < c1c + 2 * inc ? c - c1c : (fresh ? c1c + 2 * inc + c - (Co - inc) : c + inc));
         const long long src = ((n * rows + row) * HWv + hw);
@@ -309,8 +312,11 @@ extern "C" int dmn_dpn_stage_pass(float *buf, float *act, float *out,
     const long long obs = vec ? out_bs / 4 : out_bs;
     const long long total = (long long)N * Co * hwv;
     hipStream_t s = (hipStream_t)stream;
-    if (vec) hipLaunchKernelGGL(dpn_stage_pass_kernel<4>, dim3(grid_for(total)), dim3(256), 0, s, buf, act, out, mean, scale, bias, total, rows, c1c, inc, Co, hwv, obs);
-    else hipLaunchKernelGGL(dpn_stage_pass_kernel<1>, dim3(grid_for(total)), dim3(256), 0, s, buf, act, out, mean, scale, bias, total, rows, c1c, inc, Co, hwv, obs);
+    const long long per = (long long)Co * hwv;
+    if (per >= (1LL << 31) || N > 65535) return fail(-5, "dmn_dpn_stage_pass: Co*HW or N too large for the grid");
+    const dim3 grid((unsigned)((per + 255) / 256), N);
+    if (vec) hipLaunchKernelGGL(dpn_stage_pass_kernel<4>, grid, dim3(256), 0, s, buf, act, out, mean, scale, bias, total, rows, c1c, inc, Co, hwv, obs);
+    else hipLaunchKernelGGL(dpn_stage_pass_kernel<1>, grid, dim3(256), 0, s, buf, act, out, mean, scale, bias, total, rows, c1c, inc, Co, hwv, obs);
     return launch_status("dmn_dpn_stage_pass");
 }
 
