@@ -15,27 +15,29 @@
 namespace dmn {
 
 // y = max((x - mean[c]) * scale[c] + bias[c], 0),  scale = weight / sqrt(var + eps)
+// grid: x over the HWv items of one (n, c) plane, y = c, z = n: no integer division at all
 template <int VEC>
 __global__ void __launch_bounds__(256)
 bn_relu_kernel(const float *__restrict__ x, const float *__restrict__ mean,
                const float *__restrict__ scale, const float *__restrict__ bias,
                float *__restrict__ y, long long total, int C, int HWv)
 {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)((i / HWv) % C);
-        const float m = mean[c], s = scale[c], b = bias[c];
-        if (VEC == 4) {
-            const float4 v = reinterpret_cast<const float4 *>(x)[i];
-            float4 o;
-            o.x = fmaxf(__builtin_fmaf(v.x - m, s, b), 0.0f);
-            o.y = fmaxf(__builtin_fmaf(v.y - m, s, b), 0.0f);
-            o.z = fmaxf(__builtin_fmaf(v.z - m, s, b), 0.0f);
-            o.w = fmaxf(__builtin_fmaf(v.w - m, s, b), 0.0f);
-            reinterpret_cast<float4 *>(y)[i] = o;
-        } else {
-            y[i] = fmaxf(__builtin_fmaf(x[i] - m, s, b), 0.0f);
-        }
+    const int hw = blockIdx.x * blockDim.x + threadIdx.x;
+    if (hw >= HWv) return;
+    const int c = blockIdx.y;
+    const long long i = ((long long)blockIdx.z * C + c) * HWv + hw;
+    (void)total;
+    const float m = mean[c], s = scale[c], b = bias[c];
+    if (VEC == 4) {
+        const float4 v = reinterpret_cast<const float4 *>(x)[i];
+        float4 o;
+        o.x = fmaxf(__builtin_fmaf(v.x - m, s, b), 0.0f);
+        o.y = fmaxf(__builtin_fmaf(v.y - m, s, b), 0.0f);
+        o.z = fmaxf(__builtin_fmaf(v.z - m, s, b), 0.0f);
+        o.w = fmaxf(__builtin_fmaf(v.w - m, s, b), 0.0f);
+        reinterpret_cast<float4 *>(y)[i] = o;
+    } else {
+        y[i] = fmaxf(__builtin_fmaf(x[i] - m, s, b), 0.0f);
     }
 }
 
@@ -151,22 +153,20 @@ bn_relu_s2_kernel(const float *__restrict__ x, const float *__restrict__ mean,
                   const float *__restrict__ scale, const float *__restrict__ bias,
                   float *__restrict__ y, long long total, int C, int Ho, int Wo2, int W, long long x_bs)
 {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int xo = (int)(i % Wo2);
-        const long long t = i / Wo2;
-        const int oy = (int)(t % Ho);
-        const long long pl = t / Ho;                               // n * C + c
-        const int c = (int)(pl % C);
-        const float m = mean[c], s = scale[c], b = bias[c];
-        const long long n = pl / C;
-        const f32x4_t v = __builtin_nontemporal_load(
-            reinterpret_cast<const f32x4_t *>(x + n * x_bs + ((long long)c * 2 * Ho + 2 * oy) * W + 4 * xo));
-        float2 o;
-        o.x = fmaxf(__builtin_fmaf(v.x - m, s, b), 0.0f);
-        o.y = fmaxf(__builtin_fmaf(v.z - m, s, b), 0.0f);
-        *reinterpret_cast<float2 *>(y + (pl * Ho + oy) * (2 * Wo2) + 2 * xo) = o;
-    }
+    // grid: x over the Ho*Wo2 items of one (n, c) plane (32-bit math), y = c, z = n
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (unsigned)Ho * (unsigned)Wo2) return;
+    (void)total;
+    const int oy = (int)(idx / (unsigned)Wo2), xo = (int)(idx - (unsigned)oy * (unsigned)Wo2);
+    const int c = blockIdx.y;
+    const long long n = blockIdx.z;
+    const float m = mean[c], s = scale[c], b = bias[c];
+    const f32x4_t v = __builtin_nontemporal_load(
+        reinterpret_cast<const f32x4_t *>(x + n * x_bs + ((long long)c * 2 * Ho + 2 * oy) * W + 4 * xo));
+    float2 o;
+    o.x = fmaxf(__builtin_fmaf(v.x - m, s, b), 0.0f);
+    o.y = fmaxf(__builtin_fmaf(v.z - m, s, b), 0.0f);
+    *reinterpret_cast<float2 *>(y + ((n * C + c) * Ho + oy) * (2 * Wo2) + 2 * xo) = o;
 }
 
 // y = maxpool3x3/stride2/pad1( relu(bn(x)) ): the stem's bn + act + pool (dpn_model.py:186-197) in
@@ -262,13 +262,14 @@ extern "C" int dmn_bn_relu(const float *x, const float *mean, const float *scale
     if (!x || !mean || !scale || !bias || !y) return fail(-1, "dmn_bn_relu: NULL pointer");
     if (N <= 0 || C <= 0 || HW <= 0) return fail(-4, "dmn_bn_relu: bad sizes N=%d C=%d HW=%d", N, C, HW);
     hipStream_t s = (hipStream_t)stream;
-    if (HW % 4 == 0 && !(((uintptr_t)x | (uintptr_t)y) & 15)) {
-        const long long total = (long long)N * C * (HW / 4);
-        hipLaunchKernelGGL(bn_relu_kernel<4>, dim3(grid_for(total)), dim3(256), 0, s, x, mean, scale, bias, y, total, C, HW / 4);
-    } else {
-        const long long total = (long long)N * C * HW;
-        hipLaunchKernelGGL(bn_relu_kernel<1>, dim3(grid_for(total)), dim3(256), 0, s, x, mean, scale, bias, y, total, C, HW);
-    }
+    if (N > 65535 || C > 65535) return fail(-5, "dmn_bn_relu: N or C exceed the grid limits");
+    const bool vec = HW % 4 == 0 && !(((uintptr_t)x | (uintptr_t)y) & 15);
+    const int hwv = vec ? HW / 4 : HW;
+    const int bt = hwv >= 256 ? 256 : ((hwv + 63) / 64) * 64;          // small planes: fewer idle lanes
+    const dim3 grid((hwv + bt - 1) / bt, C, N);
+    const long long total = (long long)N * C * hwv;
+    if (vec) hipLaunchKernelGGL(bn_relu_kernel<4>, grid, dim3(bt), 0, s, x, mean, scale, bias, y, total, C, hwv);
+    else hipLaunchKernelGGL(bn_relu_kernel<1>, grid, dim3(bt), 0, s, x, mean, scale, bias, y, total, C, hwv);
     return launch_status("dmn_bn_relu");
 }
 
@@ -329,8 +330,11 @@ extern "C" int dmn_bn_relu_s2(const float *x, const float *mean, const float *sc
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || H % 2 || W % 4)
         return fail(-4, "dmn_bn_relu_s2: needs H %% 2 == 0 and W %% 4 == 0 (N=%d C=%d H=%d W=%d)", N, C, H, W);
     if (((uintptr_t)x & 15) || ((uintptr_t)y & 7)) return fail(-7, "dmn_bn_relu_s2: x must be 16-byte, y 8-byte aligned");
+    if (N > 65535 || C > 65535) return fail(-5, "dmn_bn_relu_s2: N or C exceed the grid limits");
     const long long total = (long long)N * C * (H / 2) * (W / 4);
-    hipLaunchKernelGGL(bn_relu_s2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+    const int per = (H / 2) * (W / 4);
+    const int bt = per >= 256 ? 256 : ((per + 63) / 64) * 64;
+    hipLaunchKernelGGL(bn_relu_s2_kernel, dim3((per + bt - 1) / bt, C, N), dim3(bt), 0, (hipStream_t)stream,
                        x, mean, scale, bias, y, total, C, H / 2, W / 4, W, x_bs);
     return launch_status("dmn_bn_relu_s2");
 }
