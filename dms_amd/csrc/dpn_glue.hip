@@ -181,13 +181,15 @@ bn_relu_maxpool_kernel(const float *__restrict__ x, const float *__restrict__ me
 {
     const int Wq = W / 4, Wo = W / 2;
     const int nchunk = (Ho + RO - 1) / RO;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int l = (int)(i % Wq);
-        const long long t = i / Wq;
-        const int oy0 = (int)(t % nchunk) * RO;
-        const long long pl = t / nchunk;                           // n * C + c
-        const int c = (int)(pl % C);
+    // grid: x over the nchunk*Wq items of one (n, c) plane (32-bit math), y = c, z = n
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+    (void)total;
+    if (idx < (unsigned)nchunk * (unsigned)Wq) {
+        const int ch = (int)(idx / (unsigned)Wq);
+        const int l = (int)(idx - (unsigned)ch * (unsigned)Wq);
+        const int oy0 = ch * RO;
+        const int c = blockIdx.y;
+        const long long pl = (long long)blockIdx.z * C + c;        // n * C + c
         const float m = mean[c], s = scale[c], b = bias[c];
         const float *xp = x + pl * H * W + 4 * l;
         auto hrow = [&](int r, float &h0, float &h1) {
@@ -347,8 +349,11 @@ extern "C" int dmn_bn_relu_maxpool(const float *x, const float *mean, const floa
         return fail(-4, "dmn_bn_relu_maxpool: needs W %% 4 == 0 (N=%d C=%d H=%d W=%d)", N, C, H, W);
     if (((uintptr_t)x & 15) || ((uintptr_t)y & 7)) return fail(-7, "dmn_bn_relu_maxpool: x must be 16-byte, y 8-byte aligned");
     const int Ho = (H - 1) / 2 + 1, RO = 4;
+    if (N > 65535 || C > 65535) return fail(-5, "dmn_bn_relu_maxpool: N or C exceed the grid limits");
     const long long total = (long long)N * C * ((Ho + RO - 1) / RO) * (W / 4);
-    hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+    const int per = ((Ho + RO - 1) / RO) * (W / 4);
+    const int bt = per >= 256 ? 256 : ((per + 63) / 64) * 64;
+    hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3((per + bt - 1) / bt, C, N), dim3(bt), 0, (hipStream_t)stream,
                        x, mean, scale, bias, y, total, C, H, W, Ho, RO);
     return launch_status("dmn_bn_relu_maxpool");
 }
