@@ -4,8 +4,10 @@
 The hot path shards over the batch of (image, query) pairs (each sample's forward is
 independent; the reference is literally batch-1, dmn.py:142), so inference needs NO collective:
 ``shard_range`` hands every rank a contiguous slice.  The only exchange step is the gradient
-all-reduce of the training step (BASELINE configs[3]); ``allreduce_gradients`` does it in a few
-large flat buckets -- xGMI is point-to-point, so few big messages beat many small ones.
+all-reduce of the training step (BASELINE configs[3]): ``OverlappedGradReducer`` keeps every
+``.grad`` as a view into a few large flat buckets and launches each bucket's RCCL all-reduce from
+an autograd hook as soon as its last gradient has been written, so the exchange overlaps the rest
+of backward (``allreduce_gradients`` is the simple after-backward form).
 """
 import os
 
@@ -39,9 +41,109 @@ def shard_range(n_items, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+class OverlappedGradReducer(object):
+    """Gradient all-reduce of the training step (BASELINE configs[3]), overlapped with backward.
+
+    * Every parameter's ``.grad`` is a VIEW into one of a few pre-allocated flat fp32 buckets
+      (``bucket_mb`` each; parameters in reverse registration order, roughly the order in which
+      backward produces their gradients), so a bucket is reduced in place: no ``torch.cat``, no
+      copy back -- the 455 MB of gradients are touched by RCCL only.
+    * A post-accumulate hook per parameter counts the bucket's gradients as they arrive; the
+      bucket's ``all_reduce(async_op=True)`` is launched from the hook of its LAST gradient, i.e.
+      while backward is still running on the layers in front of it (RCCL runs on its own stream;
+      xGMI is point-to-point, so few large buckets beat many small ones).
+    * ``finish()`` (after ``backward()``, before ``optimizer.step()``) launches what did not
+      fill up (parameters without a gradient this step), waits for all of it and averages.
+
+    Use ``reducer.zero_grad()`` instead of ``optimizer.zero_grad(set_to_none=True)``, which would
+    drop the views.  Without a process group (or world size 1) everything degrades to plain
+    local gradients.  ``launch_log`` records (bucket index, launched_during_backward) per step.
+    """
+
+    def __init__(self, params, bucket_mb=128, average=True, group=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.group, self.average = group, average
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        limit = max(int(bucket_mb * (1 << 20) // 4), 1)
+        # buckets over the parameters in reverse order
+        plan, cur, count = [], [], 0
+        for p in reversed(self.params):
+            if p.dtype != torch.float32:
+                raise TypeError("OverlappedGradReducer: fp32 parameters only")
+            if cur and count + p.numel() > limit:
+                plan.append(cur)
+                cur, count = [], 0
+            cur.append(p)
+            count += p.numel()
+        if cur:
+            plan.append(cur)
+        self.buckets, self._bucket_of, self._expected = [], {}, []
+        for bi, ps in enumerate(plan):
+            flat = torch.zeros(sum(p.numel() for p in ps), dtype=torch.float32, device=ps[0].device)
+            off = 0
+            for p in ps:
+                p.grad = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+                self._bucket_of[p] = bi
+            self.buckets.append(flat)
+            self._expected.append(len(ps))
+        self._arrived = [0] * len(self.buckets)
+        self._work = [None] * len(self.buckets)
+        self._in_backward = True
+        self.launch_log = []
+        self._handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
+
+    def _launch(self, bi):
+        if self._work[bi] is not None:
+            return
+        self.launch_log.append((bi, self._in_backward))
+        if self.world > 1:
+            self._work[bi] = dist.all_reduce(self.buckets[bi], op=dist.ReduceOp.SUM, group=self.group,
+                                             async_op=True)
+        else:
+            self._work[bi] = True
+
+    def _hook(self, p):
+        bi = self._bucket_of[p]
+        if p.grad.data_ptr() < self.buckets[bi].data_ptr() or p.grad.numel() != p.numel():
+            raise RuntimeError("OverlappedGradReducer: a .grad no longer views its bucket "
+                               "(use reducer.zero_grad(), not zero_grad(set_to_none=True))")
+        self._arrived[bi] += 1
+        if self._arrived[bi] == self._expected[bi]:
+            self._launch(bi)
+
+    def zero_grad(self):
+        for flat in self.buckets:
+            flat.zero_()
+
+    def finish(self):
+        """Wait for every bucket (launching those that never filled up) and average.
+        Returns the number of all-reduce calls of this step."""
+        self._in_backward = False
+        for bi in range(len(self.buckets)):
+            self._launch(bi)
+        for bi, w in enumerate(self._work):
+            if w is not True:
+                w.wait()
+            if self.average and self.world > 1:
+                self.buckets[bi].div_(self.world)
+        calls = len(self._work)
+        self._arrived = [0] * len(self.buckets)
+        self._work = [None] * len(self.buckets)
+        self._in_backward = True
+        return calls
+
+    def remove(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+
+
 def allreduce_gradients(params, bucket_mb=256, average=True, group=None):
-    """Sum (or average) the .grad of `params` across ranks with flat fp32 buckets.
-    Returns the number of all-reduce calls issued.  No-op without a process group."""
+    """Sum (or average) the .grad of `params` across ranks AFTER backward, in few large calls.
+    Gradients that already live in one flat buffer (OverlappedGradReducer's views) are not
+    copied; for ad-hoc use on plain .grad tensors they are flattened per bucket.  Prefer
+    OverlappedGradReducer for the training loop.  Returns the number of all-reduce calls."""
     if not dist.is_available() or not dist.is_initialized():
         return 0
     world = dist.get_world_size(group)
@@ -55,15 +157,12 @@ def allreduce_gradients(params, bucket_mb=256, average=True, group=None):
         nonlocal calls, bucket, count
         if not bucket:
             return
-        flat = torch.cat([g.reshape(-1) for g in bucket])
+        flat = torch._utils._flatten_dense_tensors(bucket)
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         if average:
             flat.div_(world)
-        off = 0
-        for g in bucket:
-            n = g.numel()
-            g.copy_(flat[off:off + n].view_as(g))
-            off += n
+        for g, r in zip(bucket, torch._utils._unflatten_dense_tensors(flat, bucket)):
+            g.copy_(r)
         calls += 1
         bucket, count = [], 0
 

@@ -27,6 +27,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+import logging
+
 from .. import ops
 from ..sru import SRU
 from .dpn import create_backbone
@@ -37,9 +39,19 @@ from .dpn import create_backbone
 # near 14 samples of 1005 columns (B=12: 0.57 vs 0.60 ms, B=16: 0.67 vs 0.61, B=32: 1.41 vs 0.62)
 MIX_SCAN_MIN_COLS = 14000
 
+_LOG = logging.getLogger("dms_amd")
 
-def _lenient_load(module, new_state, verbose=False):
-    """Copy same-name, same-size tensors; ignore the rest (dmn.py:217-223)."""
+
+def _lenient_load(module, new_state, verbose=True):
+    """Copy same-name, same-size tensors; ignore the rest (dmn.py:217-223, 457-463).
+
+    The reference skips silently.  Here every entry of the model that kept its current value
+    (absent from `new_state`, or a different size) is named in ONE log line (logger "dms_amd",
+    WARNING), together with checkpoint keys the model has no use for: the SRU parameter names
+    (``rnn_lst.{i}.weight / .bias``) belong to the third-party `sru` package and are recalled,
+    not verified, so a published ``.pth`` with other names would otherwise load as random SRU
+    weights without a word.  BatchNorm ``num_batches_tracked`` counters (absent from
+    PyTorch-0.4 checkpoints) are not reported.  Returns the list of skipped model keys."""
     state = module.state_dict()
     skipped = []
     for name in state:
@@ -48,9 +60,16 @@ def _lenient_load(module, new_state, verbose=False):
         else:
             skipped.append(name)
     nn.Module.load_state_dict(module, state)
-    if verbose and skipped:
-        print("dms_amd: %d entries kept their current values (absent or different size): %s%s"
-              % (len(skipped), ", ".join(skipped[:8]), " ..." if len(skipped) > 8 else ""))
+    if verbose:
+        report = [k for k in skipped if not k.endswith("num_batches_tracked")]
+        unused = [k for k in new_state if k not in state]
+        if report or unused:
+            def why(k):
+                return "%s (%s)" % (k, "absent" if k not in new_state else "size %s != %s" % (
+                    tuple(new_state[k].size()), tuple(state[k].size())))
+            _LOG.warning("dms_amd lenient load_state_dict: %d model entries kept their current values: %s; "
+                         "%d checkpoint entries unused: %s", len(report), ", ".join(map(why, report)) or "-",
+                         len(unused), ", ".join(unused) or "-")
     return skipped
 
 

@@ -241,8 +241,60 @@ def gen_text_and_eval():
     print("eval_iou.npz", inter.shape, float(inter.sum()), float(union.sum()))
 
 
+def gen_data_files():
+    """The reference's on-disk query formats (referit_loader.py:134-138,153-157,194-199), written by
+    the reference's OWN classes: a word_utils.Corpus built by Corpus.load_file from a vocabulary
+    file and torch.save'd as corpus.pth (pickled under its real module path), and the split lists
+    of (image, mask, phrase) triples -> tests/golden/refdata/<dataset>/ (+ tokenize_phrase ids)."""
+    import importlib.util
+    import json
+    name = "dmn_pytorch.utils.word_utils"                     # the path a real corpus.pth is pickled under
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, "dmn_pytorch", "utils", "word_utils.py"))
+    wu = importlib.util.module_from_spec(spec)
+    for parent in ("dmn_pytorch", "dmn_pytorch.utils"):       # empty packages: their __init__ imports cv2
+        pkg = types.ModuleType(parent)
+        pkg.__path__ = []
+        sys.modules.setdefault(parent, pkg)
+    sys.modules[name] = wu
+    spec.loader.exec_module(wu)
+    root = os.path.join(OUT, "refdata")
+    vocab = ["the", "left", "horse", "man", "in", "a", "red", "shirt", "standing", "second", "zebra",
+             "from", "right", "bottle", "cat", "on", "couch", "sleeping", "person", "hand", "giraffe",
+             "woman", "blue", "umbrella", "dog", "near", "tree", "big", "small", "table"]
+    phrases = {"train": ["the left horse", "man in a red shirt standing", "second zebra from the right .",
+                         "bottle", "a cat on the couch , sleeping"],
+               "val": ["woman in blue", "the big dog near the tree", "small table", "giraffe",
+                       "person hand on the left of the red umbrella near the big tree in a blue shirt standing on a table",
+                       "an unseen-word , here !"]}
+    rec = {}
+    for dataset in ("unc", "referit"):
+        d = os.path.join(root, dataset)
+        os.makedirs(d, exist_ok=True)
+        vf = os.path.join(d, "vocabulary.txt")
+        with open(vf, "w") as f:
+            f.write("\n".join(vocab) + "\n")
+        c = wu.Corpus()
+        c.load_file(vf)                                        # adds <unk>, <pad> (word_utils.py:53-60)
+        os.remove(vf)
+        torch.save(c, os.path.join(d, "corpus.pth"))
+        # PyTorch 0.4 (the reference's era) wrote the legacy, non-zip format
+        torch.save(c, os.path.join(d, "corpus_legacy.pth"), _use_new_zipfile_serialization=False)
+        for split, ps in phrases.items():
+            triples = [("COCO_train2014_%012d.jpg" % (7 * i + 1), "%d.pth" % (100 + i), p) for i, p in enumerate(ps)]
+            torch.save(triples, os.path.join(d, "%s_%s.pth" % (dataset, split)))
+            rec["%s_%s" % (dataset, split)] = {"triples": [list(t) for t in triples],
+                                               "ids_20": [c.tokenize(p, 20).tolist() for p in ps],
+                                               "ids_8": [c.tokenize(p, 8).tolist() for p in ps]}
+        rec[dataset + "_idx2word"] = c.dictionary.idx2word
+    with open(os.path.join(root, "expected.json"), "w") as f:
+        json.dump(rec, f, indent=1)
+    print("refdata:", sorted(os.listdir(os.path.join(root, "unc"))), "vocab", len(c))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "extras":
+    if len(sys.argv) > 1 and sys.argv[1] == "datafiles":
+        gen_data_files()
+    elif len(sys.argv) > 1 and sys.argv[1] == "extras":
         import_reference()
         gen_text_and_eval()
     else:

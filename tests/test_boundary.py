@@ -105,6 +105,39 @@ def test_lenient_load_state_dict_copies_only_matching_sizes():
         dms_amd.DMN(20, pretrained=True)
 
 
+def test_lenient_load_names_every_skipped_key_in_one_log_line(caplog):
+    """SRU key names are recalled from the absent `sru` package, not verified: a checkpoint that
+    names them differently must not load as random weights without a word."""
+    import logging
+    kw = dict(emb_size=8, hid_size=8, vis_size=16, num_filters=2, mixed_size=8, lang_layers=1,
+              mixed_layers=2, pretrained=False, mix_we=True, hid_mixed_size=12)
+    net = dms_amd.DMN(20, **kw)
+    ckpt = {k: v.clone() for k, v in dms_amd.DMN(20, **kw).state_dict().items()}
+    with caplog.at_level(logging.WARNING, logger="dms_amd"):
+        assert net.load_state_dict(ckpt) == []                        # complete checkpoint: silent
+    assert not caplog.records
+    # a checkpoint whose SRU layers are named differently, one wrong size, and no BN counters
+    renamed = {}
+    for k, v in ckpt.items():
+        if k.endswith("num_batches_tracked"):
+            continue
+        renamed[k.replace("mrnn.rnn_lst.0.weight", "mrnn.rnn_lst.0.W")] = v
+    renamed["langvis.emb.weight"] = torch.zeros(21, 8)
+    with caplog.at_level(logging.WARNING, logger="dms_amd"):
+        skipped = net.load_state_dict(renamed)
+    assert len(caplog.records) == 1
+    msg = caplog.records[0].getMessage()
+    assert "langvis.mrnn.rnn_lst.0.weight (absent)" in msg and "langvis.mrnn.rnn_lst.0.W" in msg
+    assert "langvis.emb.weight (size (21, 8) != (20, 8))" in msg
+    assert "num_batches_tracked" not in msg and "\n" not in msg
+    assert "langvis.mrnn.rnn_lst.0.weight" in skipped and any(k.endswith("num_batches_tracked") for k in skipped)
+    # BaseDMN's own loader reports as well
+    caplog.clear()
+    with caplog.at_level(logging.WARNING, logger="dms_amd"):
+        net.langvis.load_state_dict({})
+    assert len(caplog.records) == 1 and "emb.weight (absent)" in caplog.records[0].getMessage()
+
+
 def test_product_never_imports_oracle_or_reference():
     pat = re.compile(r"^\s*(from|import)\s+(oracle|tests|dmn_pytorch|sru\b)", re.M)
     for dirpath, _, files in os.walk(os.path.join(ROOT, "dms_amd")):

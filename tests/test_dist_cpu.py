@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from dms_amd.dist import allreduce_gradients, shard_range
+from dms_amd.dist import OverlappedGradReducer, allreduce_gradients, shard_range
 
 
 def test_shard_range_partitions_exactly():
@@ -62,3 +62,66 @@ def test_bucketed_gradient_allreduce_world2(tmp_path):
     ref = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
     assert got["calls"] >= 2                     # tiny bucket size forces several buckets
     torch.testing.assert_close(got["grad"], ref, rtol=1e-5, atol=1e-6)
+
+
+def _toy():
+    torch.manual_seed(0)
+    return torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 4), torch.nn.Tanh(),
+                               torch.nn.Linear(4, 1))
+
+
+def _overlap_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = _toy()
+        unused = torch.nn.Parameter(torch.ones(3))                  # never reaches the loss
+        params = list(model.parameters()) + [unused]
+        # 25 floats per bucket, reverse order: [unused 3 | L3.b 1 | L3.w 4 | L2.b 4] [L2.w 20 | L1.b 5] [L1.w 30]
+        red = OverlappedGradReducer(params, bucket_mb=25 * 4 / (1 << 20), average=True)
+        x = torch.arange(8 * 6, dtype=torch.float32).view(8, 6) / 10.0
+        lo, hi = shard_range(8, rank, world)
+        steps = []
+        for step in range(2):                                       # second step: views survive zero_grad()
+            red.zero_grad()
+            red.launch_log = []
+            seen = []
+            hooks = [p.register_post_accumulate_grad_hook(lambda p, i=i: seen.append(i))
+                     for i, p in enumerate(params)]
+            loss = model(x[lo:hi] * (step + 1)).pow(2).sum() / (hi - lo)
+            loss.backward()
+            log_after_backward = list(red.launch_log)
+            calls = red.finish()
+            for h in hooks:
+                h.remove()
+            flat = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+            steps.append({"grad": flat.clone(), "calls": calls, "log_bwd": log_after_backward,
+                          "log": list(red.launch_log), "seen": seen, "unused": unused.grad.clone(),
+                          "views": all(p.grad.data_ptr() >= red.buckets[red._bucket_of[p]].data_ptr() for p in params)})
+        if rank == 0:
+            torch.save(steps, out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_gradient_allreduce_world2_launches_from_hooks_and_equals_single_process(tmp_path):
+    """Buckets must be launched FROM the autograd hooks (during backward, last layers first), the
+    bucket holding a gradient-less parameter by finish(); averaged gradients must equal the
+    single-process gradient of the mean loss over the whole batch; .grad stay views of the buckets."""
+    out = str(tmp_path / "g.pt")
+    mp.spawn(_overlap_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    steps = torch.load(out)
+    x = torch.arange(8 * 6, dtype=torch.float32).view(8, 6) / 10.0
+    for step, got in enumerate(steps):
+        model = _toy()
+        model(x * (step + 1)).pow(2).mean().backward()
+        ref = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+        torch.testing.assert_close(got["grad"], ref, rtol=1e-5, atol=1e-6)
+        assert got["calls"] == 3 and got["views"]
+        # buckets 1 and 2 fill up during backward in that order (reverse layer order); bucket 0 holds
+        # the unused parameter and is launched by finish()
+        assert got["log_bwd"] == [(1, True), (2, True)]
+        assert got["log"] == [(1, True), (2, True), (0, False)]
+        # autograd's hook order: last layer's parameters first
+        assert got["seen"][0] in (4, 5) and got["seen"][-1] in (0, 1) and 6 not in got["seen"]
+        assert float(got["unused"].abs().sum()) == 0.0

@@ -16,7 +16,7 @@ import dms_amd
 from dms_amd import _lib, ops
 from oracle import dmn_ref, sru_ref
 from oracle.detgen import det_fill_state, det_ints, det_uniform
-from tests.util import base_inputs, cfg_from_golden, load_golden, rel_err
+from tests.util import assert_close_elementwise, base_inputs, cfg_from_golden, load_golden, rel_err
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -48,20 +48,25 @@ SRU_SHAPES = [(1, 1, 5, 3), (7, 3, 5, 4), (64, 1, 64, 3), (33, 2, 21, 4), (100, 
               (100, 3, 1005, 3), (257, 1, 130, 3), (0, 2, 4, 3), (25, 1, 1, 4), (23, 2, 63, 3)]
 
 
+ACTS = ["tanh", "relu", "identity"]     # upstream's use_tanh / use_relu switches (unknown default: all three run)
+SCALES = [1.0, 1.7]                     # upstream's highway scale_x (applies to k == 3 only)
+
+
 @pytest.mark.parametrize("T,B,d,k", SRU_SHAPES)
-@pytest.mark.parametrize("act", ["tanh", "relu"])
-def test_sru_fwd_matches_oracle(T, B, d, k, act):
+@pytest.mark.parametrize("act", ACTS)
+@pytest.mark.parametrize("scale_x", SCALES)
+def test_sru_fwd_matches_oracle(T, B, d, k, act, scale_x):
     u, x, bias, c0 = _case(T, B, d, k, 41)
-    h_ref, c_ref, cl_ref = sru_ref.sru_fwd_c(_np(u), _np(x), _np(bias), _np(c0), act, 1.0)
-    h, c_all, c_last = ops.sru_forward_raw(_g(u), _g(x), _g(bias), _g(c0), act, 1.0, 0,
+    h_ref, c_ref, cl_ref = sru_ref.sru_fwd_c(_np(u), _np(x), _np(bias), _np(c0), act, scale_x)
+    h, c_all, c_last = ops.sru_forward_raw(_g(u), _g(x), _g(bias), _g(c0), act, scale_x, 0,
                                            want_c=True, nchunks=1)
     np.testing.assert_allclose(h.cpu().numpy(), h_ref, rtol=1e-4, atol=2e-6)
     np.testing.assert_allclose(c_all.cpu().numpy(), c_ref, rtol=1e-4, atol=2e-6)
     np.testing.assert_allclose(c_last.cpu().numpy(), cl_ref, rtol=1e-4, atol=2e-6)
     # inference variant: no c store, c0 = NULL, only the tail of h
     h_t0 = T // 3
-    h_ref2, _, cl2 = sru_ref.sru_fwd_c(_np(u), _np(x), _np(bias), None, act, 1.0, want_c=False)
-    h2, none_c, c_last2 = ops.sru_forward_raw(_g(u), _g(x), _g(bias), None, act, 1.0, h_t0,
+    h_ref2, _, cl2 = sru_ref.sru_fwd_c(_np(u), _np(x), _np(bias), None, act, scale_x, want_c=False)
+    h2, none_c, c_last2 = ops.sru_forward_raw(_g(u), _g(x), _g(bias), None, act, scale_x, h_t0,
                                               want_c=False, nchunks=1)
     assert none_c is None and h2.shape == (T - h_t0, B, d)
     np.testing.assert_allclose(h2.cpu().numpy(), h_ref2[h_t0:], rtol=1e-4, atol=2e-6)
@@ -85,11 +90,12 @@ def test_sru_fwd_every_prefetch_depth(depth, monkeypatch):
 
 @pytest.mark.parametrize("T,B,d,k,nch", [(640, 1, 1005, 4, 10), (640, 1, 1005, 3, 7),
                                          (513, 2, 33, 3, 8), (5, 1, 9, 4, 4), (70, 1, 64, 3, 70)])
-def test_sru_fwd_time_parallel_scan_matches_oracle(T, B, d, k, nch):
+@pytest.mark.parametrize("act,scale_x", [("tanh", 1.0), ("relu", 1.7), ("identity", 1.7), ("identity", 1.0)])
+def test_sru_fwd_time_parallel_scan_matches_oracle(T, B, d, k, nch, act, scale_x):
     u, x, bias, c0 = _case(T, B, d, k, 53)
-    h_ref, _, cl_ref = sru_ref.sru_fwd_c(_np(u), _np(x), _np(bias), _np(c0), "tanh", 1.0)
+    h_ref, _, cl_ref = sru_ref.sru_fwd_c(_np(u), _np(x), _np(bias), _np(c0), act, scale_x)
     h_t0 = T // 2
-    h, _, c_last = ops.sru_forward_raw(_g(u), _g(x), _g(bias), _g(c0), "tanh", 1.0, h_t0,
+    h, _, c_last = ops.sru_forward_raw(_g(u), _g(x), _g(bias), _g(c0), act, scale_x, h_t0,
                                        want_c=False, nchunks=nch)
     np.testing.assert_allclose(h.cpu().numpy(), h_ref[h_t0:], rtol=1e-4, atol=3e-6)
     np.testing.assert_allclose(c_last.cpu().numpy(), cl_ref, rtol=1e-4, atol=3e-6)
@@ -97,17 +103,18 @@ def test_sru_fwd_time_parallel_scan_matches_oracle(T, B, d, k, nch):
 
 @pytest.mark.parametrize("T,B,d,k", [(1, 1, 5, 3), (9, 3, 5, 4), (40, 2, 17, 3), (100, 2, 1005, 4),
                                      (67, 3, 130, 3), (8, 1, 64, 4), (0, 1, 3, 3)])
-@pytest.mark.parametrize("act", ["tanh", "relu"])
-def test_sru_bwd_matches_oracle(T, B, d, k, act):
+@pytest.mark.parametrize("act", ACTS)
+@pytest.mark.parametrize("scale_x", SCALES)
+def test_sru_bwd_matches_oracle(T, B, d, k, act, scale_x):
     u, x, bias, c0 = _case(T, B, d, k, 61)
     gh = det_uniform((T, B, d), 67, 1.0)
     gl = det_uniform((B, d), 68, 1.0)
-    _, c_all, _ = sru_ref.sru_fwd_c(_np(u), _np(x), _np(bias), _np(c0), act, 1.0)
+    _, c_all, _ = sru_ref.sru_fwd_c(_np(u), _np(x), _np(bias), _np(c0), act, scale_x)
     gu_r, gx_r, gb_r, gc0_r = sru_ref.sru_bwd_c(_np(u), _np(x), _np(bias), _np(c0), c_all,
-                                                _np(gh), _np(gl), act, 1.0)
+                                                _np(gh), _np(gl), act, scale_x)
     ug, xg, bg, cg = (_g(u).requires_grad_(True), _g(x).requires_grad_(True) if x is not None else None,
                       _g(bias).requires_grad_(True), _g(c0).requires_grad_(True))
-    h, c_last = ops.sru_compute(ug, xg, bg, cg, act, 1.0)
+    h, c_last = ops.sru_compute(ug, xg, bg, cg, act, scale_x)
     ((h * _g(gh)).sum() + (c_last * _g(gl)).sum()).backward()
     np.testing.assert_allclose(ug.grad.cpu().numpy(), gu_r, rtol=2e-4, atol=1e-5)
     np.testing.assert_allclose(bg.grad.cpu().numpy(), gb_r.sum(1).reshape(-1), rtol=2e-4, atol=5e-5)
@@ -319,7 +326,8 @@ def test_hot_path_matches_reference_golden(name):
     with torch.no_grad():
         out = net.hot_path(vis.to(DEV), lang.to(DEV)).cpu()
     assert tuple(out.shape) == g["out"].shape
-    assert rel_err(out, g["out"]) < 1e-4                       # north_star tolerance
+    assert rel_err(out, g["out"]) < 1e-4                       # north_star tolerance (norm-wise)
+    assert_close_elementwise(out, g["out"])                    # ... and element by element
     if out.shape[1] == 1:                                      # thresholded mask agreement
         agree = ((out > 0) == (torch.from_numpy(g["out"]) > 0)).float().mean().item()
         assert agree >= 0.999
@@ -327,7 +335,7 @@ def test_hot_path_matches_reference_golden(name):
 
 @pytest.mark.parametrize("B,L,K,S,d", [(2, 20, 10, 100, 1005), (1, 5, 3, 12, 7), (3, 4, 1, 7, 70), (2, 6, 10, 9, 64),
                                        (1, 3, 16, 5, 130), (2, 1, 10, 1, 5), (1, 20, 10, 3, 70), (3, 20, 10, 1, 64)])
-@pytest.mark.parametrize("act", ["tanh", "relu"])
+@pytest.mark.parametrize("act", ACTS)
 def test_mix_fused_into_layer0_scan_is_bit_identical_to_mix_then_scan(B, L, K, S, d, act):
     """dmn_mix_sru_fwd == dmn_sru_fwd(dmn_mix_bcast_add(...)) bit for bit (h and c_last), with and
     without an initial state, and both match the CPU oracle on the einsum-built U0."""
@@ -426,6 +434,7 @@ def test_upsampling_module_matches_reference_golden():
     with torch.no_grad():
         y = up(x, feats).cpu()
     assert rel_err(y, g["out"]) < 1e-4
+    assert_close_elementwise(y, g["out"])
     feats = [None, None, det_uniform((1, fch[2], 13, 15), 309, 1.0).to(DEV),
              det_uniform((1, fch[1], 7, 9), 308, 1.0).to(DEV), det_uniform((1, fch[0], 4, 5), 307, 1.0).to(DEV)]
     with torch.no_grad():
@@ -573,6 +582,7 @@ def test_whole_dmn_winograd_head_matches_reference_end_to_end():
     with torch.no_grad():
         y = net(img, words).cpu()
     assert rel_err(y, g["out"]) < 1e-4
+    assert_close_elementwise(y, g["out"], rtol=2e-4)          # F(4x4) Winograd: ~1e-5 per level
 
 
 def test_whole_dmn_matches_reference_end_to_end():
@@ -591,6 +601,7 @@ def test_whole_dmn_matches_reference_end_to_end():
     assert rel_err(feats[3].cpu(), g["feat3"]) < 1e-4
     assert y.shape == (1, 1, 64, 64)
     assert rel_err(y, g["out"]) < 1e-4
+    assert_close_elementwise(y, g["out"])
     agree = ((y > 0) == (torch.from_numpy(g["out"]) > 0)).float().mean().item()
     assert agree >= 0.999
 
