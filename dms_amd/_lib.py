@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DMN_HIP_LIB", os.path.join(_HERE, "lib", "libdmn_hip.so"))
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _p = ctypes.c_void_p
 _i = ctypes.c_int

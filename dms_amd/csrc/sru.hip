@@ -17,10 +17,10 @@
 //  * 64-thread workgroups so that small column counts still spread over all 256 CUs;
 //  * gates use v_exp_f32 / v_rcp_f32 directly (sigmoid_f / tanh_f in common.h).
 #include "common.h"
+#include "sru_ring.h"
+#include <cmath>
 
 namespace dmn {
-
-struct __attribute__((packed, aligned(4))) F3 { float a, b, c; };
 
 // forward scan kernels live in sru_fwd.inl (compiled per k in sru_fwd_k3.hip / sru_fwd_k4.hip)
 void launch_sru_fwd_k3(int act, bool store_c, int depth, dim3 grid, hipStream_t s, const float *U,
@@ -84,107 +84,6 @@ sru_chunk_aggregate(const float *__restrict__ U, const float *__restrict__ bias,
 }
 
 // ------------------------------------------------------------------------------------
-// backward: reverse-time scan, same mapping; ring slot i of a block holds time tb - i
-// ------------------------------------------------------------------------------------
-struct BwdSlot { float u0, u1, u2, xv, c, gh; };
-
-template <int K>
-__device__ __forceinline__ BwdSlot load_bwd(const float *__restrict__ U, const float *__restrict__ x,
-                                            const float *__restrict__ c, const float *__restrict__ gh,
-                                            size_t ncols, int col, int t)
-{
-    const size_t e = (size_t)t * ncols + col;
-    BwdSlot s;
-    if (K == 4) {
-        const float4 v = *reinterpret_cast<const float4 *>(U + e * 4);
-        s.u0 = v.x; s.u1 = v.y; s.u2 = v.z; s.xv = v.w;
-    } else {
-        const F3 v = *reinterpret_cast<const F3 *>(U + e * 3);
-        s.u0 = v.a; s.u1 = v.b; s.u2 = v.c; s.xv = x[e];
-    }
-    s.c = c[e];
-    s.gh = gh[e];
-    return s;
-}
-
-template <int K, int ACT, int DEPTH>
-__global__ void __launch_bounds__(WAVE)
-sru_bwd_cols(const float *__restrict__ U, const float *__restrict__ x,
-             const float *__restrict__ bias, const float *__restrict__ c0,
-             const float *__restrict__ c_all, const float *__restrict__ grad_h,
-             const float *__restrict__ grad_last,
-             float *__restrict__ grad_U, float *__restrict__ grad_x,
-             float *__restrict__ grad_bias_part, float *__restrict__ grad_c0,
-             int T, int ncols, int d, float scale_x)
-{
-    const int col = blockIdx.x * WAVE + threadIdx.x;
-    if (col >= ncols) return;
-    const int j = col % d;
-    const float bf = bias[j], br = bias[j + d];
-    const float c0v = c0 ? c0[col] : 0.0f;
-    const size_t nc = (size_t)ncols;
-    const float sx = (K == 3) ? scale_x : 1.0f;
-    float cur = grad_last ? grad_last[col] : 0.0f;   // dL/dc flowing back in time
-    float gb1 = 0.0f, gb2 = 0.0f;
-
-    if (T > 0) {
-        BwdSlot ring[DEPTH];
-#pragma unroll
-        for (int i = 0; i < DEPTH; ++i) {
-            const int t = T - 1 - i;
-            ring[i] = load_bwd<K>(U, x, c_all, grad_h, nc, col, t > 0 ? t : 0);
-        }
-
-        auto step = [&](const BwdSlot s, int t, float c_prev_ring) {
-            const float g1 = sigmoid_f(s.u1 + bf);
-            const float g2 = sigmoid_f(s.u2 + br);
-            const float cval = act_fwd<ACT>(s.c);
-            const float xv = s.xv * sx;
-            const float cprev = t > 0 ? c_prev_ring : c0v;
-            const size_t e = (size_t)t * nc + col;
-            // h = (act(c) - x') * g2 + x'
-            const float gxp = s.gh * (1.0f - g2);
-            const float gg2 = s.gh * (cval - xv) * (g2 * (1.0f - g2));
-            gb2 += gg2;
-            // c = (c' - u0) * g1 + u0
-            const float gc = __builtin_fmaf(s.gh * g2, act_bwd<ACT>(cval), cur);
-            const float gu0 = gc * (1.0f - g1);
-            const float gg1 = gc * (cprev - s.u0) * (g1 * (1.0f - g1));
-            gb1 += gg1;
-            cur = gc * g1;
-            if (K == 4) {
-                *reinterpret_cast<float4 *>(grad_U + e * 4) = make_float4(gu0, gg1, gg2, gxp);
-            } else {
-                F3 o; o.a = gu0; o.b = gg1; o.c = gg2;
-                *reinterpret_cast<F3 *>(grad_U + e * 3) = o;
-                grad_x[e] = gxp * sx;
-            }
-        };
-
-        int tb = T - 1;
-        for (; tb - DEPTH + 1 >= 0; tb -= DEPTH) {
-#pragma unroll
-            for (int i = 0; i < DEPTH; ++i) {
-                const BwdSlot s = ring[i];
-                int tn = tb - i - DEPTH;
-                tn = tn > 0 ? tn : 0;              // clamped, in bounds, unused when < 0
-                ring[i] = load_bwd<K>(U, x, c_all, grad_h, nc, col, tn);
-                // c_{t-1}: slot i+1 still holds time t-1; for the last slot it is the
-                // freshly re-loaded slot 0 of the next block
-                const float cp = (i + 1 < DEPTH) ? ring[i + 1].c : ring[0].c;
-                step(s, tb - i, cp);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < DEPTH; ++i)
-            if (tb - i >= 0) step(ring[i], tb - i, (i + 1 < DEPTH) ? ring[i + 1].c : 0.0f);
-    }
-    grad_bias_part[col] = gb1;
-    grad_bias_part[nc + col] = gb2;
-    grad_c0[col] = cur;
-}
-
-// ------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------
 // tuning / test hook: DMN_SRU_DEPTH=<n> forces the prefetch depth (read on every call)
@@ -192,6 +91,26 @@ static int depth_override()
 {
     const char *e = getenv("DMN_SRU_DEPTH");
     return e ? atoi(e) : -1;
+}
+
+// Ring depth of the forward scan.  Measured on MI355X (tools/scan_bench.py depth, round 2):
+//  * launches that STORE every step (h, and c in training) are HBM-bound on a read/write mix and do
+//    best with about 4 MB of loads in flight device-wide, whatever the wave count: 503 waves (B = 32,
+//    d = 1005) depth 8 = 71.5 % of 8 TB/s vs 68.2 % at depth 32 and 48 % at depth 4; 1005 waves depth 4
+//    = 74 % vs 71 % at 16; 2000 waves (configs[4]) depth 3 = 65.8 % vs 64.2 % at 16 -- more rows in
+//    flight only compete with the stores in the memory system;
+//  * read-mostly launches (state-only scan, the last layer's tail call) want all the depth they can
+//    get: 89 % at depth 32 vs 77 % at 16 and 48 % at 8 on 503 waves.
+static int pick_depth(int nwaves, bool stores_every_step)
+{
+    if (!stores_every_step)
+        return (nwaves <= 3 * NUM_CU) ? 32 : (nwaves <= 6 * NUM_CU ? 16 : 8);
+    const double raw = 4.2e6 / ((double)nwaves * WAVE * 16.0);          // 16 B loaded per column and step
+    static const int cand[] = {3, 4, 6, 8, 16, 24, 32};
+    int best = cand[0];
+    for (int c : cand)
+        if (fabs(c - raw) < fabs(best - raw)) best = c;
+    return best;
 }
 
 static int check_common(const char *fn, const void *U, const void *x, const void *bias, int T,
@@ -222,9 +141,8 @@ extern "C" int dmn_sru_fwd(const float *U, const float *x, const float *bias, co
     if (!h && h_t0 < T) return fail(-1, "dmn_sru_fwd: h must not be NULL");
     const int ncols = B * d;
     const int nwaves = (ncols + WAVE - 1) / WAVE;
-    // bytes in flight must come from depth when there are few waves per CU
     int depth = depth_override();
-    if (depth <= 0) depth = (nwaves <= 3 * NUM_CU) ? 32 : (nwaves <= 6 * NUM_CU ? 16 : 8);
+    if (depth <= 0) depth = pick_depth(nwaves, c_all != nullptr || 2 * (long long)h_t0 < T);
     dim3 grid(nwaves);
     hipStream_t s = (hipStream_t)stream;
     if (k == 3) launch_sru_fwd_k3(act, c_all != nullptr, depth, grid, s, U, x, bias, c0, h, c_all, c_last, T, ncols, d, scale_x, h_t0, WHOLE_SEQUENCE, nullptr);
@@ -242,7 +160,7 @@ extern "C" int dmn_sru_state_fwd(const float *U2, const float *bias, const float
     const int ncols = B * d;
     const int nwaves = (ncols + WAVE - 1) / WAVE;
     int depth = depth_override();
-    if (depth <= 0) depth = (nwaves <= 3 * NUM_CU) ? 32 : (nwaves <= 6 * NUM_CU ? 16 : 8);
+    if (depth <= 0) depth = pick_depth(nwaves, false);
     launch_sru_fwd_k2(depth, dim3(nwaves), (hipStream_t)stream, U2, bias, c0, c_last, T, ncols, d);
     return launch_status("dmn_sru_state_fwd");
 }
@@ -285,42 +203,6 @@ extern "C" int dmn_sru_state_fwd_scan(const float *U2, const float *bias, const 
     return launch_status("dmn_sru_state_fwd_scan");
 }
 
-namespace dmn {
-template <int K>
-static void launch_bwd(int act, dim3 grid, hipStream_t s, const float *U, const float *x,
-                       const float *bias, const float *c0, const float *c_all,
-                       const float *grad_h, const float *grad_last, float *grad_U, float *grad_x,
-                       float *gbp, float *grad_c0, int T, int ncols, int d, float scale_x)
-{
-    constexpr int DEP = 8;
-#define DMN_BWD(A)                                                                               \
-    hipLaunchKernelGGL((sru_bwd_cols<K, A, DEP>), grid, dim3(WAVE), 0, s, U, x, bias, c0, c_all, \
-                       grad_h, grad_last, grad_U, grad_x, gbp, grad_c0, T, ncols, d, scale_x)
-    if (act == DMN_ACT_TANH) DMN_BWD(DMN_ACT_TANH);
-    else if (act == DMN_ACT_RELU) DMN_BWD(DMN_ACT_RELU);
-    else DMN_BWD(DMN_ACT_IDENTITY);
-#undef DMN_BWD
-}
-}  // namespace dmn
-
-extern "C" int dmn_sru_bwd(const float *U, const float *x, const float *bias, const float *c0,
-                           const float *c_all, const float *grad_h, const float *grad_last,
-                           float *grad_U, float *grad_x, float *grad_bias_part, float *grad_c0,
-                           int T, int B, int d, int k, int act, float scale_x, void *stream)
-{
-    if (int rc = check_common("dmn_sru_bwd", U, x, bias, T, B, d, k, act)) return rc;
-    if (((!c_all || !grad_h || !grad_U) && T > 0) || !grad_bias_part || !grad_c0)
-        return fail(-1, "dmn_sru_bwd: c_all, grad_h, grad_U, grad_bias_part, grad_c0 must not be NULL");
-    if (k == 3 && !grad_x && T > 0) return fail(-3, "dmn_sru_bwd: k == 3 needs grad_x");
-    if (k == 4 && ((uintptr_t)grad_U & 15)) return fail(-7, "dmn_sru_bwd: grad_U must be 16-byte aligned");
-    const int ncols = B * d;
-    dim3 grid((ncols + WAVE - 1) / WAVE);
-    hipStream_t s = (hipStream_t)stream;
-    if (k == 3) launch_bwd<3>(act, grid, s, U, x, bias, c0, c_all, grad_h, grad_last, grad_U, grad_x, grad_bias_part, grad_c0, T, ncols, d, scale_x);
-    else        launch_bwd<4>(act, grid, s, U, x, bias, c0, c_all, grad_h, grad_last, grad_U, grad_x, grad_bias_part, grad_c0, T, ncols, d, scale_x);
-    return launch_status("dmn_sru_bwd");
-}
-
 // ------------------------------------------------------------------------------------
 // time-parallel variant for FEW columns (e.g. B = 1: 1005 columns = 16 waves on 256 CUs):
 // chunk aggregates -> per-lane carry composition -> chunk apply.  U is read twice, which
@@ -334,25 +216,42 @@ extern "C" int dmn_sru_scan_workspace_floats(int T, int B, int d, int nchunks)
     return n > 0x7fffffffLL ? -1 : (int)n;
 }
 
+namespace dmn {
+// shared by dmn_sru_fwd_scan (caller's workspace) and dmn_sru_fwd_scan_noalloc (library scratch)
+static int fwd_scan_impl(const char *fn, const float *U, const float *x, const float *bias,
+                         const float *c0, float *h, float *c_last, float2 *carries,
+                         int T, int B, int d, int k, int act, float scale_x, int h_t0,
+                         int nchunks, hipStream_t s)
+{
+    const int ncols = B * d;
+    const int chunk_len = T > 0 ? (T + nchunks - 1) / nchunks : 1;
+    const int used = T > 0 ? (T + chunk_len - 1) / chunk_len : 1;     // chunks that hold steps
+    dim3 grid((ncols + WAVE - 1) / WAVE, used);
+    if (k == 3) hipLaunchKernelGGL((sru_chunk_aggregate<3, 8>), grid, dim3(WAVE), 0, s, U, bias, carries, T, ncols, d, chunk_len);
+    else        hipLaunchKernelGGL((sru_chunk_aggregate<4, 8>), grid, dim3(WAVE), 0, s, U, bias, carries, T, ncols, d, chunk_len);
+    if (k == 3) launch_sru_fwd_k3(act, false, 8, grid, s, U, x, bias, c0, h, nullptr, c_last, T, ncols, d, scale_x, h_t0, chunk_len, carries);
+    else        launch_sru_fwd_k4(act, false, 8, grid, s, U, x, bias, c0, h, nullptr, c_last, T, ncols, d, scale_x, h_t0, chunk_len, carries);
+    return launch_status(fn);
+}
+
+static int check_scan(const char *fn, const float *U, const float *x, const float *bias, float *h,
+                      int T, int B, int d, int k, int act, int h_t0, int nchunks)
+{
+    if (int rc = check_common(fn, U, x, bias, T, B, d, k, act)) return rc;
+    if (h_t0 < 0 || h_t0 > T) return fail(-8, "%s: h_t0=%d outside [0, T=%d]", fn, h_t0, T);
+    if (!h && h_t0 < T) return fail(-1, "%s: h must not be NULL", fn);
+    if (nchunks < 1 || nchunks > 65535) return fail(-9, "%s: nchunks=%d outside [1, 65535]", fn, nchunks);
+    return 0;
+}
+}  // namespace dmn
+
 extern "C" int dmn_sru_fwd_scan(const float *U, const float *x, const float *bias,
                                 const float *c0, float *h, float *c_last, float *workspace,
                                 int T, int B, int d, int k, int act, float scale_x, int h_t0,
                                 int nchunks, void *stream)
 {
-    if (int rc = check_common("dmn_sru_fwd_scan", U, x, bias, T, B, d, k, act)) return rc;
-    if (h_t0 < 0 || h_t0 > T) return fail(-8, "dmn_sru_fwd_scan: h_t0=%d outside [0, T=%d]", h_t0, T);
-    if (!h && h_t0 < T) return fail(-1, "dmn_sru_fwd_scan: h must not be NULL");
-    if (nchunks < 1 || nchunks > 65535) return fail(-9, "dmn_sru_fwd_scan: nchunks=%d outside [1, 65535]", nchunks);
+    if (int rc = check_scan("dmn_sru_fwd_scan", U, x, bias, h, T, B, d, k, act, h_t0, nchunks)) return rc;
     if (!workspace || ((uintptr_t)workspace & 7)) return fail(-1, "dmn_sru_fwd_scan: workspace must be non-NULL, 8-byte aligned");
-    const int ncols = B * d;
-    const int chunk_len = T > 0 ? (T + nchunks - 1) / nchunks : 1;
-    const int used = T > 0 ? (T + chunk_len - 1) / chunk_len : 1;     // chunks that hold steps
-    dim3 grid((ncols + WAVE - 1) / WAVE, used);
-    hipStream_t s = (hipStream_t)stream;
-    float2 *carries = reinterpret_cast<float2 *>(workspace);
-    if (k == 3) hipLaunchKernelGGL((sru_chunk_aggregate<3, 8>), grid, dim3(WAVE), 0, s, U, bias, carries, T, ncols, d, chunk_len);
-    else        hipLaunchKernelGGL((sru_chunk_aggregate<4, 8>), grid, dim3(WAVE), 0, s, U, bias, carries, T, ncols, d, chunk_len);
-    if (k == 3) launch_sru_fwd_k3(act, false, 8, grid, s, U, x, bias, c0, h, nullptr, c_last, T, ncols, d, scale_x, h_t0, chunk_len, carries);
-    else        launch_sru_fwd_k4(act, false, 8, grid, s, U, x, bias, c0, h, nullptr, c_last, T, ncols, d, scale_x, h_t0, chunk_len, carries);
-    return launch_status("dmn_sru_fwd_scan");
+    return fwd_scan_impl("dmn_sru_fwd_scan", U, x, bias, c0, h, c_last, reinterpret_cast<float2 *>(workspace),
+                         T, B, d, k, act, scale_x, h_t0, nchunks, (hipStream_t)stream);
 }

@@ -2,10 +2,9 @@
 // Included by sru_fwd_k3.hip / sru_fwd_k4.hip (#define DMN_SRU_K first) so that the two
 // sets of instantiations compile in parallel.  See sru.hip for the C ABI.
 #include "common.h"
+#include "sru_ring.h"
 
 namespace dmn {
-
-struct __attribute__((packed, aligned(4))) F3 { float a, b, c; };
 
 // ------------------------------------------------------------------------------------
 // forward
@@ -25,59 +24,13 @@ struct __attribute__((packed, aligned(4))) F3 { float a, b, c; };
 //        (guide section 5.7 form ii).  N = VMEM ops issued after that slot's load; stores
 //        are compiler builtins, ordered against the asm by the "memory" clobber and counted
 //        here by hand.
-constexpr float LOG2E = 1.4426950408889634f;
-
-// Cache policy of the streamed operands: U / x are read once and h / c written once per
-// launch, so both sides are non-temporal (`nt` on the loads, aux bit 1 on the stores).
-// Measured (tools/scan_bench.py policy, MI355X): in-situ k=4 63.5 -> 67.4 %, tail layer
-// 75 -> 84.6 %, config-5 stress 61.6 -> 64.4 % of 8 TB/s; either side alone gives about half.
-#ifndef DMN_LD_POLICY
-#define DMN_LD_POLICY " nt"
-#endif
-#ifndef DMN_ST_AUX
-#define DMN_ST_AUX 2
-#endif
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x3 __attribute__((ext_vector_type(3)));
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-using rsrc_t = __amdgpu_buffer_rsrc_t;
-
-__device__ __forceinline__ rsrc_t make_rsrc(const void *base)
-{
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0x7fffffff, 0x00020000);
-}
-
-// raw-buffer SRD words for the asm loads (base, stride 0, 2 GiB window, dword format)
-__device__ __forceinline__ i32x4 make_srd(const void *base)
-{
-    const unsigned long long a = (unsigned long long)base;
-    i32x4 r;
-    r.x = (int)(a & 0xffffffffull);
-    r.y = (int)((a >> 32) & 0xffffull);
-    r.z = 0x7fffffff;
-    r.w = 0x00020000;
-    return r;
-}
-
 template <int K> struct Slot;
 template <> struct Slot<4> { f32x4 u; };
 template <> struct Slot<3> { f32x3 u; float x; };
 // K = 2: state-only scan over [u0 | forget] pairs -- the steps of the LAST layer whose hidden
 // state nobody reads (dmn.py:209 keeps the last H*W steps) need neither the reset gate nor
 // the highway term, so their projection is computed for 2 of the k columns only.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <> struct Slot<2> { f32x2 u; };
-
-template <int I> struct IC { static constexpr int value = I; };
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F &&f)
-{
-    if constexpr (I < N) {
-        f(IC<I>{});
-        static_for<I + 1, N>(f);
-    }
-}
 
 // issue the loads of one time step into a ring slot (NOT waited for; see wait_slot).
 // The destination is "+v" (read-write), not "=v": tied to the register the slot already
@@ -300,7 +253,9 @@ static void launch_fwd(int depth, dim3 grid, hipStream_t s, const float *U, cons
 #define DMN_FWD(DEP)                                                                              \
     hipLaunchKernelGGL((sru_fwd_cols<K, ACT, DEP, STORE_C>), grid, dim3(WAVE), 0, s, U, x, bias, \
                        c0, h, c_all, c_last, T, ncols, d, scale_x, h_t0, chunk_len, carries)
-    if (depth <= 4) DMN_FWD(4);
+    if (depth <= 3) DMN_FWD(3);
+    else if (depth <= 4) DMN_FWD(4);
+    else if (depth <= 6) DMN_FWD(6);
     else if (depth <= 8) DMN_FWD(8);
     else if (depth <= 16) DMN_FWD(16);
     else if (depth <= 24) DMN_FWD(24);

@@ -246,12 +246,11 @@ class _SRUCompute(torch.autograd.Function):
         with torch.cuda.device(u.device):
             gu = torch.empty_like(u)
             gx = torch.empty((T, B, d), device=u.device, dtype=torch.float32) if k == 3 else None
-            gbp = torch.empty((2, B, d), device=u.device, dtype=torch.float32)
+            gbias = torch.empty((2 * d,), device=u.device, dtype=torch.float32)   # summed over t and b in-kernel
             gc0 = torch.empty((B, d), device=u.device, dtype=torch.float32)
             _lib.call("dmn_sru_bwd", _ptr(u), _ptr(x), _ptr(bias), _ptr(c0), _ptr(c_all),
-                      _ptr(grad_h), _ptr(grad_last), _ptr(gu), _ptr(gx), _ptr(gbp), _ptr(gc0),
+                      _ptr(grad_h), _ptr(grad_last), _ptr(gu), _ptr(gx), _ptr(gbias), _ptr(gc0),
                       T, B, d, k, ACT_IDS[ctx.act], float(ctx.scale_x), _stream())
-        gbias = gbp.sum(dim=1).reshape(2 * d)
         return gu, gx, gbias, (gc0 if c0 is not None else None), None, None
 
 

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DMN_ABI_VERSION 1
+#define DMN_ABI_VERSION 2
 
 /* activation ids of the SRU cell (upstream `use_tanh` / `use_relu` switches) */
 #define DMN_ACT_IDENTITY 0
@@ -88,12 +88,15 @@ int dmn_sru_state_fwd_scan(const float *U2, const float *bias, const float *c0, 
  * of the same package (autograd of dmn.py:156,204).
  *   c_all (T,B,d) saved by the forward; grad_h (T,B,d); grad_last (B,d) or NULL.
  *   grad_U (T,B,d,k); grad_x (T,B,d) iff k == 3 else NULL;
- *   grad_bias_part (2, B, d): per-(batch, column) partial sums, caller reduces over B;
+ *   grad_bias (2*d) = [forget | reset], summed over time AND batch inside the kernel (the entry
+ *   point zeroes it on `stream` first, every lane adds its column's sums with one float atomic:
+ *   no (2,B,d) partials for the caller to reduce; the order of the B additions per entry is not
+ *   fixed, so the last bit may differ between launches);
  *   grad_c0 (B, d).
  */
 int dmn_sru_bwd(const float *U, const float *x, const float *bias, const float *c0,
                 const float *c_all, const float *grad_h, const float *grad_last,
-                float *grad_U, float *grad_x, float *grad_bias_part, float *grad_c0,
+                float *grad_U, float *grad_x, float *grad_bias, float *grad_c0,
                 int T, int B, int d, int k, int act, float scale_x, void *stream);
 
 /*

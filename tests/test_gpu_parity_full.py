@@ -193,7 +193,7 @@ def test_one_training_step_of_the_whole_dmn_is_finite_and_moves_the_parameters()
           suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
 @given(T=st.integers(0, 75), B=st.integers(1, 4), d=st.integers(1, 150), k=st.sampled_from([3, 4]),
        act=st.sampled_from(["tanh", "relu", "identity"]), scale_x=st.sampled_from([1.0, 0.5, 1.7]),
-       depth=st.sampled_from(["0", "4", "8", "16", "24", "32"]), h_frac=st.sampled_from([0.0, 0.34, 1.0]),
+       depth=st.sampled_from(["0", "3", "4", "6", "8", "16", "24", "32"]), h_frac=st.sampled_from([0.0, 0.34, 1.0]),
        with_c0=st.booleans(), want_c=st.booleans(), seed=st.integers(0, 10 ** 6))
 def test_sru_fwd_shape_fuzz_matches_oracle(T, B, d, k, act, scale_x, depth, h_frac, with_c0, want_c, seed):
     """Odd d, T shorter than the register ring, B*d not a multiple of 64, every ring depth, tails."""

@@ -33,6 +33,25 @@ def run(T, B, d, k, h_t0, nch, depth, iters=10):
           % (T, B, d, k, h_t0, nch, depth or "-", ms, nbytes / ms / 1e6, nbytes / ms / 1e6 / 80), flush=True)
 
 
+def run_state(T, B, d, depth, iters=10):
+    os.environ["DMN_SRU_DEPTH"] = str(depth)
+    g = torch.Generator(device=dev).manual_seed(1)
+    u2 = torch.randn((T, B, d, 2), device=dev, generator=g)
+    bias = 0.1 * torch.randn((2 * d,), device=dev, generator=g)
+    for _ in range(2):
+        ops.sru_state(u2, bias, None, nchunks=1)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        ops.sru_state(u2, bias, None, nchunks=1)
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / iters
+    nbytes = 8 * T * B * d
+    print("state-only T=%5d B=%3d d=%4d depth=%2s : %8.3f ms  %7.1f GB/s (%.1f%% of 8 TB/s)"
+          % (T, B, d, depth, ms, nbytes / ms / 1e6, nbytes / ms / 1e6 / 80), flush=True)
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     if which in ("all", "insitu"):
@@ -65,6 +84,20 @@ if __name__ == "__main__":
                 run(5120, B, 1005, 4, 0, nch, depth)
         for nch, depth in [(1, 32), (8, 8), (32, 8), (64, 8)]:
             run(2000, 1, 1005, 3, 1900, nch, depth)
+    if which == "depth":      # round 2: shallow rings (HBM-bound launches do better with FEWER rows in flight)
+        for depth in (3, 4, 6, 8, 16, 32):
+            run(5120, 32, 1005, 3, 0, 1, depth)
+        for depth in (3, 4, 6, 8, 16, 32):
+            run(5120, 32, 1005, 4, 0, 1, depth)
+        for depth in (3, 4, 6, 8, 32):
+            run(5120, 32, 1005, 3, 5120 - 256, 1, depth)
+        for depth in (3, 4, 6, 8, 16):
+            run(4096, 128, 1000, 3, 0, 1, depth)
+        for B in (16, 8):
+            for depth in (3, 4, 6, 8, 16, 32):
+                run(5120, B, 1005, 3, 0, 1, depth)
+        for depth in (3, 4, 6, 8, 16, 32):
+            run_state(4864, 32, 1005, depth)
     if which == "policy":
         run(5120, 32, 1005, 4, 0, 1, 32)
         run(5120, 32, 1005, 3, 0, 1, 32)
