@@ -22,6 +22,7 @@ SIGNATURES = {
     "dmn_sru_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p],
     "dmn_sru_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
     "dmn_sru_fwd_scan": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _p],
+    "dmn_sru_fwd_scan_noalloc": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _p],
     "dmn_sru_state_fwd": [_p, _p, _p, _p, _i, _i, _i, _p],
     "dmn_sru_state_fwd_scan": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "dmn_sru_scan_workspace_floats": [_i, _i, _i, _i],

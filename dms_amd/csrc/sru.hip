@@ -19,6 +19,7 @@
 #include "common.h"
 #include "sru_ring.h"
 #include <cmath>
+#include <mutex>
 
 namespace dmn {
 
@@ -253,5 +254,58 @@ extern "C" int dmn_sru_fwd_scan(const float *U, const float *x, const float *bia
     if (int rc = check_scan("dmn_sru_fwd_scan", U, x, bias, h, T, B, d, k, act, h_t0, nchunks)) return rc;
     if (!workspace || ((uintptr_t)workspace & 7)) return fail(-1, "dmn_sru_fwd_scan: workspace must be non-NULL, 8-byte aligned");
     return fwd_scan_impl("dmn_sru_fwd_scan", U, x, bias, c0, h, c_last, reinterpret_cast<float2 *>(workspace),
+                         T, B, d, k, act, scale_x, h_t0, nchunks, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------
+// dmn_sru_fwd_scan for callers that cannot allocate (HIP graph capture, tight serving loops):
+// the chunk-carry workspace lives in a file-scope device array instead of caller memory.
+// `scan_scratch` is a HOST-SIDE STAND-IN for the symbol, not a device address: the per-device
+// address comes from hipGetSymbolAddress (once per device, that device current) and only that
+// pointer is ever handed to a kernel.
+// ------------------------------------------------------------------------------------
+namespace dmn {
+constexpr int SCAN_SCRATCH_FLOATS = DMN_SCAN_SCRATCH_FLOATS;       // 4 MiB on every GPU the library runs on
+static __device__ __align__(256) float scan_scratch[SCAN_SCRATCH_FLOATS];
+constexpr int MAX_DEVICES = 64;
+static std::mutex scratch_mutex;
+static float *scratch_dev_ptr[MAX_DEVICES];                        // per device: each GPU holds its own copy
+
+// device address of the CURRENT device's copy of scan_scratch (looked up on the first call per device)
+static int scan_scratch_ptr(const char *fn, float **out)
+{
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail((int)e, "%s: hipGetDevice: %s", fn, hipGetErrorString(e));
+    if (dev < 0 || dev >= MAX_DEVICES) return fail(-10, "%s: device index %d outside [0, %d)", fn, dev, MAX_DEVICES);
+    std::lock_guard<std::mutex> lock(scratch_mutex);
+    if (!scratch_dev_ptr[dev]) {
+        float *p = nullptr;
+        e = hipGetSymbolAddress(reinterpret_cast<void **>(&p), HIP_SYMBOL(scan_scratch));
+        if (e != hipSuccess || !p)
+            return fail(e != hipSuccess ? (int)e : -10, "%s: hipGetSymbolAddress(scan_scratch): %s", fn, hipGetErrorString(e));
+        scratch_dev_ptr[dev] = p;
+    }
+    *out = scratch_dev_ptr[dev];
+    return 0;
+}
+}  // namespace dmn
+
+extern "C" int dmn_sru_fwd_scan_noalloc(const float *U, const float *x, const float *bias,
+                                        const float *c0, float *h, float *c_last,
+                                        int T, int B, int d, int k, int act, float scale_x, int h_t0,
+                                        int nchunks, void *stream)
+{
+    const char *fn = "dmn_sru_fwd_scan_noalloc";
+    if (int rc = check_scan(fn, U, x, bias, h, T, B, d, k, act, h_t0, nchunks)) return rc;
+    const long long need = 2LL * nchunks * B * d;
+    if (need > SCAN_SCRATCH_FLOATS)
+        return fail(-11, "%s: 2*nchunks*B*d = %lld floats exceed the built-in scratch of %d floats "
+                         "(use dmn_sru_fwd_scan with a caller workspace, or fewer chunks)", fn, need, SCAN_SCRATCH_FLOATS);
+    float *ws = nullptr;
+    if (int rc = scan_scratch_ptr(fn, &ws)) return rc;
+    // nothing in the scratch has to start at zero: the aggregate kernel writes every (chunk, column)
+    // pair before the scan kernel (same stream) reads it
+    return fwd_scan_impl(fn, U, x, bias, c0, h, c_last, reinterpret_cast<float2 *>(ws),
                          T, B, d, k, act, scale_x, h_t0, nchunks, (hipStream_t)stream);
 }

@@ -13,7 +13,8 @@
  *   - Return value: 0 = ok; < 0 = rejected argument (nothing launched);
  *     > 0 = hipError_t from the launch.  dmn_last_error() gives the message of the last
  *     failure on the calling thread.  No C++ exception crosses the boundary.
- *   - Re-entrant, no global mutable state besides the thread-local error string.
+ *   - Re-entrant, no global mutable state besides the thread-local error string (one exception:
+ *     dmn_sru_fwd_scan_noalloc, whose per-GPU scratch array is shared by all its callers).
  */
 #ifndef DMN_HIP_H
 #define DMN_HIP_H
@@ -64,6 +65,25 @@ int dmn_sru_fwd_scan(const float *U, const float *x, const float *bias, const fl
                      float *h, float *c_last, float *workspace,
                      int T, int B, int d, int k, int act, float scale_x, int h_t0,
                      int nchunks, void *stream);
+
+/*
+ * dmn_sru_fwd_scan WITHOUT a caller workspace, for callers that cannot allocate device memory
+ * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has
+ * no counterpart in the reference.  Same arguments, kernels and results (bit for bit) as
+ * dmn_sru_fwd_scan; the chunk carries live in a 4 MiB file-scope `static __device__` array that
+ * every GPU the library runs on holds until the process ends.  The entry point calls no hipMalloc /
+ * hipFree / allocating routine.
+ *   Limit: 2 * nchunks * B * d <= DMN_SCAN_SCRATCH_FLOATS, else status -11 and nothing is launched
+ *   (e.g. batch-1 serving: 2 * 32 * 1005 = 64 320 floats; 16 samples x 32 chunks still fit).
+ *   All calls on one GPU share that GPU's array: calls that OVERLAP on one GPU (two streams, two
+ *   threads) race on it -- serialise them, or use dmn_sru_fwd_scan with separate workspaces.
+ *   Nothing in the array has to start at zero (every carry is written before it is read).
+ */
+#define DMN_SCAN_SCRATCH_FLOATS (1 << 20)
+int dmn_sru_fwd_scan_noalloc(const float *U, const float *x, const float *bias, const float *c0,
+                             float *h, float *c_last,
+                             int T, int B, int d, int k, int act, float scale_x, int h_t0,
+                             int nchunks, void *stream);
 
 /*
  * State-only scan: the cell state after T steps, nothing else.  Same reference interface as
