@@ -37,7 +37,11 @@ __device__ __forceinline__ void static_for_t(F &&f)
 // LX > 0: L == LX exactly -- the word loop is fully unrolled and P never goes through LDS: the
 // pixel's L*K values stay spread over the lanes' prefetch registers and each step pulls its K
 // values into scalar registers with v_readlane (constant lane index), no memory wait at all.
-template <int ACT, int KX, int LX>
+// WB: how many of the step loop's h stores the per-pixel wait may leave outstanding (a compile-time
+// bucket <= L chosen by the host: 20, 8 or 0).  It used to be picked by `if (L >= 20) .. else if (L >= 8)`
+// INSIDE the pixel loop; hipcc then copied the prefetch registers into the branch's own registers
+// right before the asm wait, i.e. while their loads could still be in flight (check_asm_waits.py).
+template <int ACT, int KX, int LX, int WB>
 __global__ void __launch_bounds__(WAVE)
 mix_sru_fwd_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
                    const float *__restrict__ Pt, const float *__restrict__ Wp, int ldw,
@@ -70,7 +74,6 @@ mix_sru_fwd_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
 
     const float bf2 = -MS_LOG2E * bias[j], br2 = -MS_LOG2E * bias[j + d];
     float cur = c0 ? c0[col] : 0.0f;
-    const float *Ap = A + (long long)b * S * M4 + 4 * j;
     const float *pb = Pt + (long long)b * S * L * K;          // uniform
     float *hp = h + col;
     const long long hstride = (long long)B * d;
@@ -107,7 +110,7 @@ mix_sru_fwd_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
             asm volatile("global_load_dword %0, %1, %2" : "+v"(pre[i]) : "v"(poff[i]), "s"(psrc) : "memory");
     };
     // wait until at most N younger VMEM operations (the h stores since the fetch) are outstanding
-#define DMN_MS_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(a_nx), "+v"(pre[0]), "+v"(pre[1]), "+v"(pre[2]), "+v"(pre[3]) : : "memory")
+#define DMN_MS_WAIT(N) asm volatile("s_waitcnt vmcnt(%5)" : "+v"(a_nx), "+v"(pre[0]), "+v"(pre[1]), "+v"(pre[2]), "+v"(pre[3]) : "n"(N) : "memory")
     // LX path: with at most one wave per SIMD occupancy is moot, so the lane's L rows of Bt live in
     // registers (4*LX VGPRs) and the step loop touches no memory but the h store
     float4 btr[LX > 0 ? LX : 1];
@@ -182,14 +185,203 @@ mix_sru_fwd_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
             __builtin_nontemporal_store(hv, hs + (long long)t * hstride);
         }
         }
-        // the L stores above are younger than the fetch: leave (at most) that many outstanding
-        if (L >= 20) DMN_MS_WAIT(20);
-        else if (L >= 8) DMN_MS_WAIT(8);
-        else DMN_MS_WAIT(0);
+        // the L stores above are younger than the fetch: leave (at most) WB <= L of them outstanding
+        DMN_MS_WAIT(WB);
         buf ^= 1;
     }
 #undef DMN_MS_WAIT
     if (c_last) c_last[col] = cur;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K = 10 filters, L = 20 words (the model's own shape): TWO cooperating waves per 64 columns.
+//
+// The single-wave kernel above is bound by one wave's in-order issue (~280 cycles per step) while
+// half of the 1024 SIMDs idle (512 waves at B = 32).  The cell state needs only the gates (u0,
+// forget); the hidden state needs (reset, highway) and act(c_t).  So a 128-thread workgroup runs
+//   wave 0 ("state"):  q01 = A.xy + Bt.xy + sum_k Wp01[k] P[t,k]  ->  f, c_t, act(c_t)  ->  LDS
+//   wave 1 ("output"): q23 = A.zw + Bt.zw + sum_k Wp23[k] P[t,k]  ->  r, h_t = (act(c_t) - hw) r + hw -> HBM
+// each with half of the packed FMAs (10 instead of 20 per step) and half of the transcendentals.
+// The hand-over is one pixel (20 steps) deep: the state wave writes pixel s into LDS buffer s & 1 while
+// the output wave consumes pixel s - 1 from the other buffer; ONE s_barrier per pixel.  The two waves
+// sit on different SIMDs of one CU.  Every operation is the single-wave kernel's, in the same
+// order per gate, so h stays bit-identical to dmn_mix_bcast_add + dmn_sru_fwd.
+//
+// Store alignment: h rows are d = 1005 floats (4020 B), so a 64-lane store that starts at column
+// 64 m of sample b starts at byte (b d + 64 m) * 4 of its time step's row -- on no particular boundary;
+// the PMC counters showed +11 % HBM write traffic from the partial 64-byte segments at both ends of
+// every store.  When B d is a multiple of 16 floats (every row of h starts 64-byte aligned) the column
+// windows of sample b are shifted left by (b d) mod 16 columns, so that every store covers whole
+// 64-byte segments (the first window's lanes below column 0 ride along on the clamped column 0).
+//
+// Workgroup = 4 waves = two independent (state, output) pairs on two adjacent column windows: a CU
+// then receives whole workgroups whose four waves go to its four SIMDs, one each.  With 2-wave
+// workgroups (two per CU) the second workgroup's waves often landed on the SIMDs the first one already
+// occupied: 0.655 ms instead of 0.396 ms at B = 32 (tools/mix_sru_bench.py).
+constexpr int MP_PAIRS = 2;
+template <int ACT>
+__global__ void __launch_bounds__(2 * MP_PAIRS * WAVE)
+mix_sru_pair_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
+                    const float *__restrict__ Pt, const float *__restrict__ Wp, int ldw,
+                    const float *__restrict__ bias, const float *__restrict__ c0,
+                    float *__restrict__ h, float *__restrict__ c_last, int B, int S, int d, int shift_on)
+{
+    constexpr int KX = 10, LX = 20, LK = KX * LX, PREG = 4;
+    __shared__ float hand_all[MP_PAIRS][2][LX][WAVE];          // act(c_t) of one pixel, double-buffered, per pair
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int role = wave & 1;                                // 0 = state wave, 1 = output wave
+    float (*hand)[LX][WAVE] = hand_all[wave >> 1];
+    const int win = (int)blockIdx.x * MP_PAIRS + (wave >> 1); // 64-column window of this pair
+    const int b = blockIdx.y;
+    const int sh = shift_on ? (int)(((long long)b * d) & 15) : 0;
+    // lanes (and whole windows) outside [0, d) stay alive on the clamped column (same inputs, same
+    // arithmetic, same bits to the same address as the lane that owns it): they carry their share of
+    // the P prefetch and every wave meets every barrier
+    const int jraw = win * WAVE + lane - sh;
+    const int j = jraw < 0 ? 0 : (jraw < d ? jraw : d - 1);
+    const int M4 = 4 * d;
+    const int col = b * d + j;
+    const int g0 = 2 * role;                                  // this wave's gate pair: (0,1) or (2,3)
+
+    f32x2_t w[KX];
+#pragma unroll
+    for (int k = 0; k < KX; ++k)
+        w[k] = (f32x2_t){Wp[(long long)(4 * j + g0) * ldw + k], Wp[(long long)(4 * j + g0 + 1) * ldw + k]};
+    f32x2_t btr[LX];
+#pragma unroll
+    for (int t = 0; t < LX; ++t) {
+        const float2 v = *reinterpret_cast<const float2 *>(Bt + ((long long)t * B + b) * M4 + 4 * j + g0);
+        btr[t] = (f32x2_t){v.x, v.y};
+    }
+    const float bg2 = -MS_LOG2E * bias[j + role * d];         // forget bias (state) / reset bias (output)
+
+    // per-pixel prefetch, one PIXEL ahead, inline asm that hipcc does not count (see the kernel above)
+    unsigned poff[PREG];
+#pragma unroll
+    for (int i = 0; i < PREG; ++i) {
+        const int idx = i * WAVE + lane;
+        poff[i] = (unsigned)(idx < LK ? idx : LK - 1) * 4u;
+    }
+    const unsigned aoff = (unsigned)(4 * j + g0) * 4u;
+    const float *Ab = A + (long long)b * S * M4;
+    const float *pb = Pt + (long long)b * S * LK;
+    f32x2_t a_nx = {0.0f, 0.0f};
+    float pre[PREG] = {0.0f, 0.0f, 0.0f, 0.0f};
+    auto fetch_pixel = [&](int sp) {
+        const int sc = sp < S ? sp : S - 1;
+        const float *asrc = Ab + (long long)sc * M4;
+        const float *psrc = pb + (long long)sc * LK;
+        asm volatile("global_load_dwordx2 %0, %1, %2" : "+v"(a_nx) : "v"(aoff), "s"(asrc) : "memory");
+#pragma unroll
+        for (int i = 0; i < PREG; ++i)
+            asm volatile("global_load_dword %0, %1, %2" : "+v"(pre[i]) : "v"(poff[i]), "s"(psrc) : "memory");
+    };
+#define DMN_MP_WAIT(N) asm volatile("s_waitcnt vmcnt(%5)" : "+v"(a_nx), "+v"(pre[0]), "+v"(pre[1]), "+v"(pre[2]), "+v"(pre[3]) : "n"(N) : "memory")
+    // LDS traffic of this wave done, then meet the partner (the h stores are NOT waited for)
+#define DMN_MP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+    // this wave's gate pairs of G consecutive steps, q[i] = A + Bt[t0+i] + sum_k w[k] * P[t0+i, k].
+    // A lone wave issues in order, and one step's 10 packed FMAs are ONE dependent chain (the order of
+    // the sum over k is part of the bit-identity contract): G independent chains are interleaved so
+    // that the chain's latency, not just its issue slots, is covered.  Same for the transcendentals.
+    constexpr int G = 4;
+    static_assert(LX % G == 0, "steps are processed in groups of G");
+    auto gates = [&](auto gc, const f32x2_t ac, const float (&hold)[PREG], f32x2_t (&q)[G]) {
+        constexpr int t0 = decltype(gc)::value * G;
+#pragma unroll
+        for (int i = 0; i < G; ++i) q[i] = (f32x2_t){ac.x + btr[t0 + i].x, ac.y + btr[t0 + i].y};
+        // v_readlane -> SGPR -> v_pk_fma back to back costs an s_nop per FMA (VALU-writes-SGPR hazard):
+        // the P values of TWO filters x G steps are pulled into 2G distinct SGPRs first, then consumed
+#pragma unroll
+        for (int k = 0; k < KX; k += 2) {
+            float pv[2][G];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < G; ++i) {
+                    const int idx = (t0 + i) * KX + k + kk;
+                    pv[kk][i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(
+                        __builtin_bit_cast(int, hold[idx / WAVE]), idx % WAVE));
+                }
+            __builtin_amdgcn_sched_barrier(0);                // keep the readlanes ahead of their FMAs
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < G; ++i)
+                    q[i] = __builtin_elementwise_fma(w[k + kk], (f32x2_t){pv[kk][i], pv[kk][i]}, q[i]);
+        }
+    };
+
+    fetch_pixel(0);
+    DMN_MP_WAIT(0);
+    if (role == 0) {
+        float cur = c0 ? c0[col] : 0.0f;
+        for (int s = 0; s < S; ++s) {
+            const f32x2_t ac = a_nx;
+            float hold[PREG];
+#pragma unroll
+            for (int i = 0; i < PREG; ++i) hold[i] = pre[i];
+            fetch_pixel(s + 1);
+            float *hb = &hand[s & 1][0][lane];
+            static_for_t<0, LX / G>([&](auto gc) {
+                constexpr int t0 = decltype(gc)::value * G;
+                f32x2_t q[G];                                              // (u0, forget)
+                gates(gc, ac, hold, q);
+                float f[G], cs[G];
+#pragma unroll
+                for (int i = 0; i < G; ++i) f[i] = fast_exp2(__builtin_fmaf(q[i].y, -MS_LOG2E, bg2));
+#pragma unroll
+                for (int i = 0; i < G; ++i) f[i] = fast_rcp(1.0f + f[i]);
+#pragma unroll
+                for (int i = 0; i < G; ++i) {
+                    cur = __builtin_fmaf(cur - q[i].x, f[i], q[i].x);
+                    cs[i] = cur;
+                }
+#pragma unroll
+                for (int i = 0; i < G; ++i) hb[(t0 + i) * WAVE] = act_fwd<ACT>(cs[i]);
+            });
+            DMN_MP_WAIT(0);                                   // this wave stores nothing to global memory
+            DMN_MP_BARRIER();                                 // pixel s is in LDS; the partner has left pixel s - 1
+        }
+        DMN_MP_BARRIER();                                     // pairs with the partner's last pixel
+        if (c_last && jraw == j) c_last[col] = cur;
+    } else {
+        float *hp = h + col;
+        const long long hstride = (long long)B * d;
+        DMN_MP_BARRIER();                                     // pixel 0 is in LDS
+        for (int s = 0; s < S; ++s) {
+            const f32x2_t ac = a_nx;
+            float hold[PREG];
+#pragma unroll
+            for (int i = 0; i < PREG; ++i) hold[i] = pre[i];
+            fetch_pixel(s + 1);
+            const float *hb = &hand[s & 1][0][lane];
+            float av[LX];
+#pragma unroll
+            for (int t = 0; t < LX; ++t) av[t] = hb[t * WAVE];
+            float *hs = hp + (long long)s * LX * hstride;
+            static_for_t<0, LX / G>([&](auto gc) {
+                constexpr int t0 = decltype(gc)::value * G;
+                f32x2_t q[G];                                              // (reset, highway)
+                gates(gc, ac, hold, q);
+                float r[G];
+#pragma unroll
+                for (int i = 0; i < G; ++i) r[i] = fast_exp2(__builtin_fmaf(q[i].x, -MS_LOG2E, bg2));
+#pragma unroll
+                for (int i = 0; i < G; ++i) r[i] = fast_rcp(1.0f + r[i]);
+#pragma unroll
+                for (int i = 0; i < G; ++i) {
+                    const float hv = __builtin_fmaf(av[t0 + i] - q[i].y, r[i], q[i].y);
+                    __builtin_nontemporal_store(hv, hs + (long long)(t0 + i) * hstride);
+                }
+            });
+            DMN_MP_WAIT(20);                                  // the 20 h stores above are younger than the fetch
+            DMN_MP_BARRIER();                                 // done reading pixel s; pixel s + 1 is in LDS
+        }
+    }
+#undef DMN_MP_WAIT
+#undef DMN_MP_BARRIER
 }
 
 }  // namespace dmn
@@ -212,18 +404,39 @@ extern "C" int dmn_mix_sru_fwd(const float *A, const float *Bt, const float *Pt,
     if (act != DMN_ACT_TANH && act != DMN_ACT_RELU && act != DMN_ACT_IDENTITY)
         return fail(-2, "dmn_mix_sru_fwd: unknown activation %d", act);
     hipStream_t s = (hipStream_t)stream;
+    // the model's own shape: two cooperating waves per 64 columns (DMN_MIX_SRU_PAIR=0: the single-wave kernel)
+    const char *pe = getenv("DMN_MIX_SRU_PAIR");
+    if (K == 10 && L == 20 && !(pe && atoi(pe) == 0)) {
+        const int shift_on = ((long long)B * d) % 16 == 0 && (d + 15 + WAVE - 1) / WAVE == (d + WAVE - 1) / WAVE;
+        const int nwin = (d + (shift_on ? 15 : 0) + WAVE - 1) / WAVE;
+        dim3 pgrid((nwin + MP_PAIRS - 1) / MP_PAIRS, B);
+#define DMN_MP(ACTV) hipLaunchKernelGGL((mix_sru_pair_kernel<ACTV>), pgrid, dim3(2 * MP_PAIRS * WAVE), 0, s, A, Bt, Pt, Wp, ldw, \
+                                        bias, c0, h, c_last, B, S, d, shift_on)
+        if (act == DMN_ACT_TANH) DMN_MP(DMN_ACT_TANH);
+        else if (act == DMN_ACT_RELU) DMN_MP(DMN_ACT_RELU);
+        else DMN_MP(DMN_ACT_IDENTITY);
+#undef DMN_MP
+        return launch_status("dmn_mix_sru_fwd");
+    }
     dim3 grid((d + WAVE - 1) / WAVE, B);
-#define DMN_MS(ACTV, KXV, LXV) hipLaunchKernelGGL((mix_sru_fwd_kernel<ACTV, KXV, LXV>), grid, dim3(WAVE), lds, s, A, Bt, Pt, \
-                                                  Wp, ldw, bias, c0, h, c_last, B, L, K, S, d)
-#define DMN_MSA(KXV, LXV)                                                \
-    do {                                                                 \
-        if (act == DMN_ACT_TANH) DMN_MS(DMN_ACT_TANH, KXV, LXV);         \
-        else if (act == DMN_ACT_RELU) DMN_MS(DMN_ACT_RELU, KXV, LXV);    \
-        else DMN_MS(DMN_ACT_IDENTITY, KXV, LXV);                         \
+#define DMN_MS(ACTV, KXV, LXV, WBV) hipLaunchKernelGGL((mix_sru_fwd_kernel<ACTV, KXV, LXV, WBV>), grid, dim3(WAVE), lds, s, A, Bt, Pt, \
+                                                       Wp, ldw, bias, c0, h, c_last, B, L, K, S, d)
+#define DMN_MSA(KXV, LXV, WBV)                                                \
+    do {                                                                      \
+        if (act == DMN_ACT_TANH) DMN_MS(DMN_ACT_TANH, KXV, LXV, WBV);         \
+        else if (act == DMN_ACT_RELU) DMN_MS(DMN_ACT_RELU, KXV, LXV, WBV);    \
+        else DMN_MS(DMN_ACT_IDENTITY, KXV, LXV, WBV);                         \
     } while (0)
-    if (K == 10 && L == 20) DMN_MSA(10, 20);          // the model's default: num_filters 10, 20-word queries
-    else if (K == 10) DMN_MSA(10, 0);
-    else DMN_MSA(0, 0);
+#define DMN_MSW(KXV)                                  \
+    do {                                              \
+        if (L >= 20) DMN_MSA(KXV, 0, 20);             \
+        else if (L >= 8) DMN_MSA(KXV, 0, 8);          \
+        else DMN_MSA(KXV, 0, 0);                      \
+    } while (0)
+    if (K == 10 && L == 20) DMN_MSA(10, 20, 20);      // single-wave variant of the model's default shape
+    else if (K == 10) DMN_MSW(10);
+    else DMN_MSW(0);
+#undef DMN_MSW
 #undef DMN_MSA
 #undef DMN_MS
     return launch_status("dmn_mix_sru_fwd");

@@ -120,6 +120,125 @@ tap_gather_kernel(const float *__restrict__ Z, const float *__restrict__ bias, f
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Tiled variant for power-of-two widths W = 16 .. 128 (the four wide head levels), round 2.
+// The sweep kernel above spends 71 % of its wave cycles in s_waitcnt (rocprofv3 SQ_WAIT_ANY) with the
+// VALU 5 % busy: every lane walks its rows one memory round trip at a time, three loads per tap (8-byte
+// + two neighbour dwords), 94 VGPRs.  Here a 256-thread workgroup takes a BAND of 1024 consecutive
+// floats of every tap plane -- NR = 1024 / W low-res rows; for fixed (b, tap) the (co, row) planes are
+// one contiguous slab, so a band is 4 KiB of contiguous memory per tap, whole planes when H <= NR --
+// with ONE 16-byte load per lane and tap (nine independent loads in flight per lane), does the
+// horizontal pass in registers (the two neighbour columns come from the adjacent lanes), hands the
+// three horizontally finished rows to the lanes of the rows above and below through LDS, and writes
+// the 2 x 8 outputs of its four columns.  When a plane is taller than a band, lanes 0 .. W/2-1 also
+// fetch the band's two halo rows; consecutive bands are mapped to the SAME XCD (workgroups are dealt to
+// the 8 XCDs round-robin), so that those re-reads are L2 hits.
+template <int W>
+__global__ void __launch_bounds__(256)
+tap_gather_tile_kernel(const float *__restrict__ Z, const float *__restrict__ bias, float *__restrict__ out,
+                       int Cout, int H, long long out_bs, int nbands, int total, int xcd_chunk)
+{
+    constexpr int NR = 1024 / W, LPR = W / 4, W2 = 2 * W;
+    __shared__ float hl[3][NR + 2][W2];                       // horizontally finished rows, band + 2 halo rows
+    const int t = threadIdx.x;
+    const int vb = (int)(blockIdx.x % 8) * xcd_chunk + (int)(blockIdx.x / 8);
+    if (vb >= total) return;                                  // whole workgroup: uniform
+    const int b = vb / nbands, band = vb - b * nbands;
+    const long long slabrows = (long long)Cout * H;
+    const long long tapstride = slabrows * W;
+    const float *zb = Z + (long long)b * 9 * tapstride;
+    const int R0 = band * NR;
+
+    // horizontal pass of one low-res row segment: h[ky][c] = sum_kx upx(z[ky*3+kx])[2*c0 + c + kx - 1]
+    auto hpass = [&](long long R, int c0, float (&h)[3][8]) {
+        const float *zr = zb + R * W + c0;
+        f32x4_t z[9];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+            z[tap] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(zr + tap * tapstride));
+        const bool el = c0 == 0, er = c0 + 4 == W;           // row edges: clamp (bilinear) and zero (conv pad)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) h[ky][c] = 0.0f;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const f32x4_t v = z[ky * 3 + kx];
+                const float lft = __shfl_up(v.w, 1), rgt = __shfl_down(v.x, 1);
+                float zl[6] = {el ? v.x : lft, v.x, v.y, v.z, v.w, er ? v.w : rgt};
+                float u[10];
+                u[0] = el ? 0.0f : (0.75f * zl[0] + 0.25f * zl[1]);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    u[1 + 2 * m] = 0.25f * zl[m] + 0.75f * zl[m + 1];
+                    u[2 + 2 * m] = 0.75f * zl[m + 1] + 0.25f * zl[m + 2];
+                }
+                u[9] = er ? 0.0f : (0.25f * zl[4] + 0.75f * zl[5]);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) h[ky][c] += u[c + kx];
+            }
+        }
+    };
+    auto put = [&](int row, int c0, const float (&h)[3][8]) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            float4 *dst = reinterpret_cast<float4 *>(&hl[ky][row][2 * c0]);
+            dst[0] = make_float4(h[ky][0], h[ky][1], h[ky][2], h[ky][3]);
+            dst[1] = make_float4(h[ky][4], h[ky][5], h[ky][6], h[ky][7]);
+        }
+    };
+
+    const int rr = t / LPR, c0 = (t % LPR) * 4;
+    const long long R = (long long)R0 + rr;
+    const int co = (int)(R / H), r = (int)(R - (long long)co * H);
+    float Rc[3][8];
+    hpass(R, c0, Rc);
+    put(rr + 1, c0, Rc);
+    if (H > NR && t < 2 * LPR) {                              // halo rows (same plane only)
+        const int bottom = t / LPR;
+        const long long Rh = bottom ? (long long)R0 + NR : (long long)R0 - 1;
+        const int rfirst = (int)((long long)R0 % H);          // row of the band's first line inside its plane
+        if (bottom ? (rfirst + NR < H) : (rfirst > 0)) {
+            float Rh3[3][8];
+            hpass(Rh, c0, Rh3);
+            put(bottom ? NR + 1 : 0, c0, Rh3);
+        }
+    }
+    __syncthreads();
+
+    // vertical pass; rows outside the plane: clamp for the bilinear terms, zero for the conv padding
+    const bool top = r == 0, bot = r + 1 == H;
+    const float bv = bias ? bias[co] : 0.0f;
+    float o0[8], o1[8];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const float4 m0 = *reinterpret_cast<const float4 *>(&hl[0][rr][2 * c0 + 4 * half]);
+        const float4 m1 = *reinterpret_cast<const float4 *>(&hl[1][rr][2 * c0 + 4 * half]);
+        const float4 p1 = *reinterpret_cast<const float4 *>(&hl[1][rr + 2][2 * c0 + 4 * half]);
+        const float4 p2 = *reinterpret_cast<const float4 *>(&hl[2][rr + 2][2 * c0 + 4 * half]);
+        const float am0[4] = {m0.x, m0.y, m0.z, m0.w}, am1[4] = {m1.x, m1.y, m1.z, m1.w};
+        const float ap1[4] = {p1.x, p1.y, p1.z, p1.w}, ap2[4] = {p2.x, p2.y, p2.z, p2.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 4 * half + e;
+            const float Rm0 = top ? Rc[0][c] : am0[e], Rm1 = top ? Rc[1][c] : am1[e];
+            const float Rp1 = bot ? Rc[1][c] : ap1[e], Rp2 = bot ? Rc[2][c] : ap2[e];
+            o0[c] = bv + (top ? 0.0f : (0.75f * Rm0 + 0.25f * Rc[0][c]))
+                       + (0.25f * Rm1 + 0.75f * Rc[1][c])
+                       + (0.75f * Rc[2][c] + 0.25f * Rp2);
+            o1[c] = bv + (0.25f * Rm0 + 0.75f * Rc[0][c])
+                       + (0.75f * Rc[1][c] + 0.25f * Rp1)
+                       + (bot ? 0.0f : (0.25f * Rc[2][c] + 0.75f * Rp2));
+        }
+    }
+    float *p0 = out + (long long)b * out_bs + ((long long)co * 2 * H + 2 * r) * W2 + 2 * c0;   // plane = (2H) x (2W)
+    float *p1 = p0 + W2;
+    store_stream4(p0, o0[0], o0[1], o0[2], o0[3]);
+    store_stream4(p0 + 4, o0[4], o0[5], o0[6], o0[7]);
+    store_stream4(p1, o1[0], o1[1], o1[2], o1[3]);
+    store_stream4(p1 + 4, o1[4], o1[5], o1[6], o1[7]);
+}
+
 // Z[b, r, p] = sum_c w[r, c] * in[b, c, p], r = 0..8, in = cat(x, feat) over channels (never built).
 // VEC pixels per lane; the weight reads are uniform (scalar loads).
 template <int VEC>
@@ -179,6 +298,28 @@ extern "C" int dmn_tap_upsample_gather(const float *Z, const float *bias, float 
         return fail(-4, "dmn_tap_upsample_gather: bad sizes B=%d Cout=%d H=%d W=%d", B, Cout, H, W);
     if ((long long)B * Cout >= (1LL << 31) / 4)
         return fail(-5, "dmn_tap_upsample_gather: B*Cout=%lld too large", (long long)B * Cout);
+    hipStream_t s = (hipStream_t)stream;
+    // tiled kernel: power-of-two widths 16 .. 128, bands of 1024 / W rows that tile the (co, row) slab
+    // and either hold whole planes or divide one (DMN_TAP_TILE=0: the sweep kernel, for A/B runs)
+    {
+        const char *te = getenv("DMN_TAP_TILE");
+        const bool wok = W == 16 || W == 32 || W == 64 || W == 128;
+        const int NR = wok ? 1024 / W : 1;
+        if (wok && !(te && atoi(te) == 0) && ((long long)Cout * H) % NR == 0 && (H % NR == 0 || NR % H == 0)
+            && !(((uintptr_t)Z | (uintptr_t)out) & 15) && (long long)B * Cout * H / NR < (1LL << 30)) {
+            const int nbands = (int)((long long)Cout * H / NR);
+            const int total = B * nbands;
+            const int xcd_chunk = (total + 7) / 8;
+            dim3 tgrid((unsigned)xcd_chunk * 8);
+#define DMN_TILE(WV) hipLaunchKernelGGL(tap_gather_tile_kernel<WV>, tgrid, dim3(256), 0, s, Z, bias, out, Cout, H, out_bs, nbands, total, xcd_chunk)
+            if (W == 16) DMN_TILE(16);
+            else if (W == 32) DMN_TILE(32);
+            else if (W == 64) DMN_TILE(64);
+            else DMN_TILE(128);
+#undef DMN_TILE
+            return launch_status("dmn_tap_upsample_gather");
+        }
+    }
     const bool two = (W % 2 == 0) && !(((uintptr_t)Z & 7) | ((uintptr_t)out & 15));
     if (!two && ((uintptr_t)out & 7))
         return fail(-5, "dmn_tap_upsample_gather: out must be 8-byte aligned");
@@ -193,7 +334,6 @@ extern "C" int dmn_tap_upsample_gather(const float *Z, const float *bias, float 
     const int chunks = (H + RB - 1) / RB;
     if (chunks > 65535) return fail(-5, "dmn_tap_upsample_gather: H=%d too large", H);
     dim3 grid((unsigned)blocks, chunks);
-    hipStream_t s = (hipStream_t)stream;
     if (two) hipLaunchKernelGGL(tap_gather_kernel<2>, grid, dim3(256), 0, s, Z, bias, out, B, Cout, H, W, RB, out_bs);
     else hipLaunchKernelGGL(tap_gather_kernel<1>, grid, dim3(256), 0, s, Z, bias, out, B, Cout, H, W, RB, out_bs);
     return launch_status("dmn_tap_upsample_gather");

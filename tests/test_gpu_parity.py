@@ -362,7 +362,10 @@ def test_hot_path_matches_reference_golden(name):
 
 
 @pytest.mark.parametrize("B,L,K,S,d", [(2, 20, 10, 100, 1005), (1, 5, 3, 12, 7), (3, 4, 1, 7, 70), (2, 6, 10, 9, 64),
-                                       (1, 3, 16, 5, 130), (2, 1, 10, 1, 5), (1, 20, 10, 3, 70), (3, 20, 10, 1, 64)])
+                                       (1, 3, 16, 5, 130), (2, 1, 10, 1, 5), (1, 20, 10, 3, 70), (3, 20, 10, 1, 64),
+                                       # K = 10, L = 20 with B*d a multiple of 16: the two-wave kernel with its
+                                       # 64-byte-aligned (shifted) column windows, incl. windows that start below column 0
+                                       (16, 20, 10, 3, 1005), (32, 20, 10, 2, 1005), (2, 20, 10, 4, 1000), (4, 20, 10, 2, 100)])
 @pytest.mark.parametrize("act", ACTS)
 def test_mix_fused_into_layer0_scan_is_bit_identical_to_mix_then_scan(B, L, K, S, d, act):
     """dmn_mix_sru_fwd == dmn_sru_fwd(dmn_mix_bcast_add(...)) bit for bit (h and c_last), with and
@@ -519,8 +522,13 @@ def test_head_final_equals_conv_then_out_layer(B, Cx, Cf, H, W, Co):
                                               (2, 16, 16, 16, 16, 32), (1, 3, 2, 1, 1, 2), (1, 2, 2, 1, 4, 2),
                                               (3, 5, 4, 7, 12, 9), (1, 3, 3, 2, 2, 2), (2, 4, 3, 6, 10, 5),
                                               (1, 8, 8, 8, 24, 4), (1, 0, 3, 5, 3, 2), (2, 3, 3, 40, 20, 3),
-                                              (1, 2, 1, 33, 130, 2)])
-def test_tap_gemm_level_matches_cat_upsample_conv(B, Cx, Cf, H, W, Cout):
+                                              (1, 2, 1, 33, 130, 2),
+                                              # power-of-two widths: the tiled kernel -- whole planes per band
+                                              # (H <= 1024 / W), bands with halo rows (H > 1024 / W), non-square
+                                              (1, 3, 2, 32, 32, 4), (1, 2, 2, 64, 64, 2), (1, 1, 1, 128, 128, 2),
+                                              (2, 2, 1, 8, 32, 4), (1, 2, 2, 32, 64, 3), (1, 2, 1, 128, 16, 2),
+                                              (2, 3, 1, 16, 128, 3)])
+def test_tap_gemm_level_matches_cat_upsample_conv(B, Cx, Cf, H, W, Cout, monkeypatch):
     """nine tap matrices at low resolution (library GEMM) + gather at high resolution ==
     conv3x3(upsample2x(cat)) (dmn.py:324,337-338), incl. odd sizes, 1-pixel maps, empty sources."""
     x = det_uniform((B, Cx, H, W), 91, 1.0).to(DEV)
@@ -537,6 +545,15 @@ def test_tap_gemm_level_matches_cat_upsample_conv(B, Cx, Cf, H, W, Cout):
     assert got.shape == want.shape and rel_err(got, want) < 2e-6
     got_nobias = ops.tap_upsample_gather(Z, None)
     assert rel_err(got_nobias + bias.view(1, -1, 1, 1), want) < 2e-6
+    # the row-sweep kernel (all shapes) and the tiled kernel (power-of-two widths) agree to rounding,
+    # also when the output is a channel slice of a larger buffer (out_bs > Cout * 4 * H * W)
+    monkeypatch.setenv("DMN_TAP_TILE", "0")
+    sweep = ops.tap_upsample_gather(Z, bias)
+    monkeypatch.delenv("DMN_TAP_TILE")
+    assert rel_err(got, sweep) < 1e-6
+    big = torch.full((B, Cout + 3, 2 * H, 2 * W), 7.0, device=DEV)
+    ops.tap_upsample_gather(Z, bias, out=big[:, :Cout])
+    assert torch.equal(big[:, :Cout], got) and bool((big[:, Cout:] == 7.0).all())
 
 
 @pytest.mark.parametrize("B,Cx,Cf,H,W,Co", [(2, 3, 5, 4, 8, 6), (1, 2, 3, 3, 5, 4), (1, 4, 0, 1, 1, 3), (2, 8, 8, 16, 16, 32),

@@ -22,7 +22,7 @@ def timeit(fn, iters=10):
     return a.elapsed_time(b) / iters
 
 
-for B in (4, 8, 12, 16, 32, 64):
+for B in (2, 4, 8, 12, 16, 32, 64):
     A = torch.randn(B, S, 4 * d, device=dev)
     Bt = torch.randn(L, B, 4 * d, device=dev)
     P = torch.randn(L, B, K, S, device=dev)
@@ -34,6 +34,12 @@ for B in (4, 8, 12, 16, 32, 64):
         return ops.sru_forward_raw(u, None, bias, None, "tanh", 1.0)
 
     t_pair = timeit(pair)
-    t_fused = timeit(lambda: ops.mix_sru_fwd(A, Bt, P, W, bias, None, "tanh"))
-    print("B=%2d: mix + scan %.3f ms   fused %.3f ms" % (B, t_pair, t_fused), flush=True)
+    # the fused call includes the (L,B,K,S) -> (B,S,L,K) transpose of P (a small torch copy)
+    os.environ["DMN_MIX_SRU_PAIR"] = "0"
+    t_single = timeit(lambda: ops.mix_sru_fwd(A, Bt, P, W, bias, None, "tanh"))
+    os.environ["DMN_MIX_SRU_PAIR"] = "1"
+    t_two = timeit(lambda: ops.mix_sru_fwd(A, Bt, P, W, bias, None, "tanh"))
+    same = torch.equal(ops.mix_sru_fwd(A, Bt, P, W, bias, None, "tanh")[0], pair()[0])
+    print("B=%2d: mix + scan %.3f ms   fused single-wave %.3f ms   fused two-wave %.3f ms   bit-identical %s"
+          % (B, t_pair, t_single, t_two, same), flush=True)
     del A, Bt, P, W
