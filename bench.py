@@ -196,12 +196,14 @@ class LaunchTimer(object):
 def measured_traffic(kernel_label):
     """HBM bytes per launch from the committed PMC passes (profiles/traffic_r1.json; separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 FETCH x2 correction) or None."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "traffic_r1.json")) as f:
-            table = json.load(f)
-        return table[kernel_label]["hbm_bytes"]
-    except (OSError, KeyError, ValueError):
-        return None
+    for name in ("traffic_r2.json", "traffic_r1.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                table = json.load(f)
+            return table[kernel_label]["hbm_bytes"]
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 def build_model(device, high_res=True):
@@ -241,9 +243,34 @@ def serving_latency(net, device, reps=30):
             "hip_graph_ms": round(replay, 3), "graph_equals_eager": same}
 
 
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _median_time(fn, reps):
+    times = []
+    for i in range(reps + 1):
+        t0 = time.perf_counter()
+        out = fn()
+        if i:                                              # first pass is warm-up
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    return times[len(times) // 2], out
+
+
 def cpu_baseline_dmn(net, reps, threads):
-    """CPU oracle on batch-1 queries of the same workload: torch-CPU DPN92 + reference-
-    shaped hot path (oracle.dmn_ref, plain-C SRU scan) + reference-shaped upsampling."""
+    """CPU oracle (= the reference path's arithmetic: torch-CPU DPN92 + oracle.dmn_ref's reference-shaped
+    hot path with the plain-C SRU scan + reference-shaped upsampling) on this box's host cores, on
+    bounded samples of SURVEY 8(d)'s cases: 512 px high-res at B = 1 (the headline `value`) and B = 8,
+    configs[0] (320 px low-res, B = 1), and the SRU-only scan of configs[4] scaled to B = 8."""
+    import numpy as np
     from oracle import dmn_ref, sru_ref
     torch.set_num_threads(threads)
     sru_ref.set_threads(threads)
@@ -255,32 +282,74 @@ def cpu_baseline_dmn(net, reps, threads):
     g = torch.Generator().manual_seed(SEED)
     img = torch.randn(1, 3, 512, 512, generator=g)
     words = torch.randint(0, 1000, (1, 20), generator=g)
-    times, out = [], None
+
+    def query(net_, P_, cfg_, im, wd):
+        vis, feats = net_.langvis.base(im)
+        x = dmn_ref.hot_path(P_, vis, wd, cfg_, use_c=True)
+        return dmn_ref.upsampling(P_, x, feats, 5) if cfg_["high_res"] else x
+
     with torch.no_grad():
-        for i in range(reps + 1):
-            t0 = time.perf_counter()
-            vis, feats = cpu_net.langvis.base(img)
-            x = dmn_ref.hot_path_single(P, vis, words, cfg, use_c=True)
-            out = dmn_ref.upsampling(P, x, feats, 5)
-            if i:                                          # first pass is warm-up
-                times.append(time.perf_counter() - t0)
-    times.sort()
-    med = times[len(times) // 2]
-    return {"value": round(1.0 / med, 4), "unit": "queries/s", "cores": threads, "kind": "port",
-            "sample": "%d batch-1 512px high-res queries (median of %d after 1 warm-up): torch-CPU "
-                      "DPN92 + oracle/dmn_ref hot path (C scan, OpenMP) + oracle upsampling"
-                      % (reps, reps),
-            "seconds_per_query": round(med, 3)}, (img, words, out)
+        med, out = _median_time(lambda: query(cpu_net, P, cfg, img, words), reps)
+        # 512 px high-res, batch 8 (backbone and head batched, hot path per sample as in the reference)
+        img8 = torch.randn(8, 3, 512, 512, generator=g)
+        words8 = torch.randint(0, 1000, (8, 20), generator=g)
+        med8, _ = _median_time(lambda: query(cpu_net, P, cfg, img8, words8), 3)
+        # configs[0]: 320 px low-res, batch 1 (the reference's own CPU-runnable case)
+        low = build_model("cpu", high_res=False)
+        Pl = dict(low.state_dict())
+        cfgl = dict(cfg, high_res=False)
+        img3 = torch.randn(1, 3, 320, 320, generator=g)
+        medl, _ = _median_time(lambda: query(low, Pl, cfgl, img3, words), 5)
+    # SRU-only scan, configs[4] scaled to B = 8: T = 4096, d = 1000, k = 3
+    T, B, d = 4096, 8, 1000
+    rng = np.random.default_rng(SEED)
+    u = rng.standard_normal((T, B, d, 3), dtype=np.float32)
+    xx = rng.standard_normal((T, B, d), dtype=np.float32)
+    bias = (0.1 * rng.standard_normal(2 * d)).astype(np.float32)
+    meds, _ = _median_time(lambda: sru_ref.sru_fwd_c(u, xx, bias, None, "tanh", 1.0, want_c=False), 5)
+    scan_gbs = 20.0 * T * B * d / meds / 1e9
+    cb = {"value": round(1.0 / med, 4), "unit": "queries/s", "cores": threads, "kind": "port",
+          "host_cpus": os.cpu_count(), "cpu_model": _cpu_model(), "threads_used": threads,
+          "sample": "%d batch-1 512px high-res queries (median of %d after 1 warm-up): torch-CPU "
+                    "DPN92 + oracle/dmn_ref hot path (C scan, OpenMP) + oracle upsampling"
+                    % (reps, reps),
+          "seconds_per_query": round(med, 3),
+          "cases": {
+              "dmn512_highres_b1": {"queries_per_s": round(1.0 / med, 4), "reps": reps},
+              "dmn512_highres_b8": {"queries_per_s": round(8.0 / med8, 4), "reps": 3},
+              "dmn320_lowres_b1 (configs[0])": {"queries_per_s": round(1.0 / medl, 4), "reps": 5},
+              "sru_scan_T4096_B8_d1000_k3": {"GBs_algorithmic_20B": round(scan_gbs, 2),
+                                             "ms": round(meds * 1e3, 2), "reps": 5}}}
+    return cb, (img, words, out)
 
 
 def run_train320(args, device, rank, world, timer):
     """BASELINE configs[3]: low-res 320 px training step, batch 64 per GPU: forward -> bilinear
     upsample of the logits to the mask size -> BCEWithLogits vs random {0,1} masks
     (train.py:275-283) -> backward -> gradient all-reduce (RCCL) -> Adam(lr 1e-5) (train.py:71,242)."""
+    import threading
     import torch.nn.functional as F
-    from dms_amd.dist import allreduce_gradients
+    from dms_amd.dist import OverlappedGradReducer
+
+    # heartbeat: the first step compiles / finds MIOpen kernels for every DPN92 convolution (forward,
+    # backward-data, backward-weights) and can take minutes with several ranks on one card; a silent
+    # process is taken for hung (round 1's 2-rank rehearsal was killed that way)
+    phase = {"name": "building the model", "t0": time.perf_counter(), "stop": False}
+
+    def heartbeat():
+        while not phase["stop"]:
+            time.sleep(20)
+            if not phase["stop"]:
+                print("[train320] rank %d alive: %s (%.0f s)" % (rank, phase["name"], time.perf_counter() - phase["t0"]),
+                      file=sys.stderr, flush=True)
+
+    threading.Thread(target=heartbeat, daemon=True).start()
+    os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")          # bound the find phase (heuristic pick, no exhaustive search)
     net = build_model(device, high_res=False).train()
     opt = torch.optim.Adam(net.parameters(), lr=1e-5)
+    # gradients live in flat buckets; each bucket's RCCL all-reduce starts from an autograd hook while
+    # backward is still running (dms_amd/dist.py)
+    red = OverlappedGradReducer(list(net.parameters()), bucket_mb=128, average=True) if world > 1 else None
     B = args.batch
     g = torch.Generator(device=device).manual_seed(SEED + rank)
     img = torch.randn((B, 3, 320, 320), device=device, generator=g)
@@ -290,30 +359,36 @@ def run_train320(args, device, rank, world, timer):
     ar_ms = []
 
     def step():
-        opt.zero_grad(set_to_none=True)
+        if red is not None:
+            red.zero_grad()
+        else:
+            opt.zero_grad(set_to_none=True)
         out = net(img, words)
         out = F.interpolate(out, size=mask.shape[-2:], mode="bilinear", align_corners=False)
         loss = crit(out, mask)
         loss.backward()
-        if world > 1:
-            if os.environ.get("DMN_BENCH_VERBOSE"):
-                torch.cuda.synchronize()
-                print("[train320] rank %d backward done, all-reduce..." % rank, file=sys.stderr, flush=True)
+        if red is not None:
+            # what is left of the exchange after backward has returned (the exposed part)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            allreduce_gradients(list(net.parameters()), bucket_mb=256, average=True)
+            red.finish()
             b.record()
             ar_ms.append((a, b))
         opt.step()
         return loss
 
     for i in range(args.warmup):
+        phase["name"] = "warm-up step %d (MIOpen find / kernel compilation on the first one)" % i
+        print("[train320] rank %d starting warm-up step %d" % (rank, i), file=sys.stderr, flush=True)
         loss = step()
         torch.cuda.synchronize()
         print("[train320] rank %d warm-up step %d done" % (rank, i), file=sys.stderr, flush=True)
+    phase["name"] = "timed steps"
     if world > 1:
         dist.barrier()
     timer.records, ar_ms[:] = [], []
+    if red is not None:
+        red.launch_log = []
     timer.enabled = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -323,6 +398,7 @@ def run_train320(args, device, rank, world, timer):
         dist.barrier()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
+    phase["stop"] = True
     assert bool(torch.isfinite(loss))
     el = torch.tensor([elapsed], dtype=torch.float64,
                       device=device if dist.is_initialized() and dist.get_backend() == "nccl" else "cpu")
@@ -341,11 +417,15 @@ def run_train320(args, device, rank, world, timer):
             "config": {"workload": "DMN low-res 320px training step (BASELINE configs[3]): BCEWithLogits, "
                                    "Adam lr 1e-5, train() mode", "batch_per_gpu": B,
                        "global_batch": B * world, "grad_allreduce_MB": round(nparams * 4 / 1e6, 1),
-                       "parallelism": "data parallel, one bucketed fp32 all-reduce per step"},
+                       "parallelism": "data parallel; gradients in flat 128 MB buckets, each bucket's all-reduce "
+                                      "launched from an autograd hook during backward"},
             "roofline": {"bound": "hbm", "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": dom["frac_of_8TBs"], "traffic": None,
-                         "kernel": dom["kernel"], "avg_launch_ms": dom["avg_ms"]},
-            "allreduce_ms": round(sum(a.elapsed_time(b) for a, b in ar_ms) / max(len(ar_ms), 1), 3) if ar_ms else None,
+                         "unit": "GB/s", "frac": dom["frac_of_8TBs"], "traffic": measured_traffic(dom["kernel"]),
+                         "kernel": dom["kernel"], "avg_launch_ms": dom["avg_ms"],
+                         "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"]},
+            "allreduce_exposed_ms": round(sum(a.elapsed_time(b) for a, b in ar_ms) / max(len(ar_ms), 1), 3) if ar_ms else None,
+            "allreduce_buckets_launched_during_backward": (round(sum(1 for _, inb in red.launch_log if inb) / float(args.steps), 2) if red is not None else None),
+            "allreduce_buckets": (len(red.buckets) if red is not None else None),
             "hip_kernels_ms_per_step": round(sum(r["total_ms"] for r in kernels) / args.steps, 3),
             "hip_kernels": kernels, "loss": float(loss)}
     if rank == 0:
@@ -384,7 +464,7 @@ def main():
                     help="(image, query) pairs per GPU (default 32; 64 for train320)")
     ap.add_argument("--workload", default="dmn512", choices=["dmn512", "msru_stress", "train320"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-reps", type=int, default=25)
+    ap.add_argument("--cpu-reps", type=int, default=15)
     ap.add_argument("--no-head-link", action="store_true",
                     help="A/B switch: compact pyramid taps and the two-GEMM head levels instead of the "
                          "backbone writing each tap into the head's [x | feat] buffer")

@@ -94,19 +94,23 @@ static int depth_override()
     return e ? atoi(e) : -1;
 }
 
-// Ring depth of the forward scan.  Measured on MI355X (tools/scan_bench.py depth, round 2):
+// Ring depth of the forward scan.  Measured on MI355X (tools/scan_bench.py depth / depth2, round 2, with
+// the stores left out of the counted waits -- sru_ring.h -- so a wait also covers the stores issued
+// since the slot's load and a ring is worth about half its slots on a launch that stores every step):
 //  * launches that STORE every step (h, and c in training) are HBM-bound on a read/write mix and do
-//    best with about 4 MB of loads in flight device-wide, whatever the wave count: 503 waves (B = 32,
-//    d = 1005) depth 8 = 71.5 % of 8 TB/s vs 68.2 % at depth 32 and 48 % at depth 4; 1005 waves depth 4
-//    = 74 % vs 71 % at 16; 2000 waves (configs[4]) depth 3 = 65.8 % vs 64.2 % at 16 -- more rows in
-//    flight only compete with the stores in the memory system;
+//    best with about 8 MB of ring device-wide, whatever the wave count: 503 waves (B = 32, d = 1005)
+//    depth 16 = 74.9 % of 8 TB/s (k = 3) / 72.9 % (k = 4) vs 58 % at depth 8 and 68-70 % at 24-32;
+//    1005 waves depth 8 = 73.3 % vs 69.5 % at 16 (training forward with c: 75.8 % k = 3, 71.7 % k = 4);
+//    252 waves depth 24-32 = 63.5 %; 2000 waves (configs[4]) depth 3 = 67.0 % vs 65.7 % at 4 and
+//    64.4 % at 6 -- more rows in flight only compete with the stores in the memory system;
 //  * read-mostly launches (state-only scan, the last layer's tail call) want all the depth they can
 //    get: 89 % at depth 32 vs 77 % at 16 and 48 % at 8 on 503 waves.
 static int pick_depth(int nwaves, bool stores_every_step)
 {
     if (!stores_every_step)
         return (nwaves <= 3 * NUM_CU) ? 32 : (nwaves <= 6 * NUM_CU ? 16 : 8);
-    const double raw = 4.2e6 / ((double)nwaves * WAVE * 16.0);          // 16 B loaded per column and step
+    if (nwaves >= 6 * NUM_CU) return 3;
+    const double raw = 8.0e6 / ((double)nwaves * WAVE * 16.0);          // 16 B loaded per column and step
     static const int cand[] = {3, 4, 6, 8, 16, 24, 32};
     int best = cand[0];
     for (int c : cand)

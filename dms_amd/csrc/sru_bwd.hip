@@ -66,6 +66,26 @@ __device__ __forceinline__ void wait_bslot(BSlot<3> &s)
     asm volatile("s_waitcnt vmcnt(%4)" : "+v"(s.u), "+v"(s.x), "+v"(s.c), "+v"(s.gh) : "n"(n) : "memory");
 }
 
+// The wide gradient stores go out as inline asm WITH two wait states attached.  gfx950 reads the data
+// registers of a store of more than 64 bits late: a VALU instruction issued directly behind the store
+// that writes one of them can win.  hipcc pads global_store_dwordx3/x4 for this but assumes a buffer
+// store with an SGPR soffset is safe, and its scheduler likes to recycle the data registers in the very
+// next instruction.  Seen in round 2 at T = 2000 x 64 320 columns: ~100 wavefronts per launch (the
+// fourth wave of a CU, last quad of each 16-lane row) stored the NEXT step's `1 + exp2(..)` in exactly
+// the components whose register the next instruction rewrote (tools/bwd_repeat.py); components
+// rewritten one instruction later were never hit.  The s_nop inside the statement cannot be moved.
+#ifndef DMN_BWD_STORE_NOP
+#define DMN_BWD_STORE_NOP "\n\ts_nop 1"
+#endif
+__device__ __forceinline__ void store_wide(u32x4 o, i32x4 srd, unsigned off, unsigned soff)
+{
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt" DMN_BWD_STORE_NOP :: "v"(o), "v"(off), "s"(srd), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void store_wide(u32x3 o, i32x4 srd, unsigned off, unsigned soff)
+{
+    asm volatile("buffer_store_dwordx3 %0, %1, %2, %3 offen nt" DMN_BWD_STORE_NOP :: "v"(o), "v"(off), "s"(srd), "s"(soff) : "memory");
+}
+
 // what a computed step leaves open until c_{t-1} is known
 struct Pending { float gc, u0, dg1, gu0, gg2, gxp; };
 
@@ -80,7 +100,7 @@ sru_bwd_cols(const float *__restrict__ U, const float *__restrict__ x,
              int T, int ncols, int d, float scale_x)
 {
     constexpr int NLD = (K == 3) ? 4 : 3;      // VMEM loads per step
-    constexpr int NST = (K == 3) ? 2 : 1;      // VMEM stores per step
+    constexpr int NST = DMN_VMCNT_COUNT_STORES ? ((K == 3) ? 2 : 1) : 0;   // VMEM stores per step that a wait may leave outstanding (sru_ring.h)
     const int col = blockIdx.x * WAVE + threadIdx.x;
     if (col >= ncols) return;
     const int j = col % d;
@@ -130,16 +150,16 @@ sru_bwd_cols(const float *__restrict__ U, const float *__restrict__ x,
 
         // finish the pending step (time tp) now that c_{tp-1} = cprev is known, and store its
         // gradients at row offsets sU / sX from the store descriptors
-        auto finish = [&](float cprev, rsrc_t rGU, rsrc_t rGX, unsigned sU, unsigned sX) {
+        auto finish = [&](float cprev, i32x4 rGU, rsrc_t rGX, unsigned sU, unsigned sX) {
             const float gg1 = pend.gc * (cprev - pend.u0) * pend.dg1;
             gb1 += gg1;
             if (K == 4) {
                 const u32x4 o = {__float_as_uint(pend.gu0), __float_as_uint(gg1), __float_as_uint(pend.gg2),
                                  __float_as_uint(pend.gxp)};
-                __builtin_amdgcn_raw_buffer_store_b128(o, rGU, offU, sU, DMN_ST_AUX);
+                store_wide(o, rGU, offU, sU);
             } else {
                 const u32x3 o = {__float_as_uint(pend.gu0), __float_as_uint(gg1), __float_as_uint(pend.gg2)};
-                __builtin_amdgcn_raw_buffer_store_b96(o, rGU, offU, sU, DMN_ST_AUX);
+                store_wide(o, rGU, offU, sU);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pend.gxp * sx), rGX, offX, sX, DMN_ST_AUX);
             }
         };
@@ -182,7 +202,7 @@ sru_bwd_cols(const float *__restrict__ U, const float *__restrict__ x,
             // stores of steps 1 .. i-1 (step 0 has nothing pending)
             {
                 const int tl = T - DEPTH;                                   // lowest time of this block (>= 0)
-                const rsrc_t rGU = make_rsrc(pGU + (size_t)(tl + 1) * strideU);
+                const i32x4 rGU = srd_uniform(pGU + (size_t)(tl + 1) * strideU);
                 const rsrc_t rGX = make_rsrc(pGX + (size_t)(tl + 1) * strideX);
                 const int base = tl - DEPTH > 0 ? tl - DEPTH : 0;
                 const BwdSrds r = srds_at(base);
@@ -198,7 +218,7 @@ sru_bwd_cols(const float *__restrict__ U, const float *__restrict__ x,
             // steady state (every time loaded is >= 0): slot i is followed by DEPTH-1 full steps
             for (done = DEPTH; done + 2 * DEPTH <= T; done += DEPTH) {
                 const int tl = T - done - DEPTH;
-                const rsrc_t rGU = make_rsrc(pGU + (size_t)(tl + 1) * strideU);
+                const i32x4 rGU = srd_uniform(pGU + (size_t)(tl + 1) * strideU);
                 const rsrc_t rGX = make_rsrc(pGX + (size_t)(tl + 1) * strideX);
                 const BwdSrds r = srds_at(tl - DEPTH);
                 static_for<0, DEPTH>([&](auto ic) {
@@ -212,7 +232,7 @@ sru_bwd_cols(const float *__restrict__ U, const float *__restrict__ x,
             // last full block (if any is left): same counts, clamped loads
             for (; done + DEPTH <= T; done += DEPTH) {
                 const int tl = T - done - DEPTH;
-                const rsrc_t rGU = make_rsrc(pGU + (size_t)(tl + 1) * strideU);
+                const i32x4 rGU = srd_uniform(pGU + (size_t)(tl + 1) * strideU);
                 const rsrc_t rGX = make_rsrc(pGX + (size_t)(tl + 1) * strideX);
                 const int base = tl - DEPTH > 0 ? tl - DEPTH : 0;
                 const BwdSrds r = srds_at(base);
@@ -228,7 +248,8 @@ sru_bwd_cols(const float *__restrict__ U, const float *__restrict__ x,
         // last partial block (no loads): at least the rest of the previous block's (or the
         // prologue's) loads follow slot i.  Stores are addressed from row 0 (times < DEPTH + 1).
         {
-            const rsrc_t rGU = make_rsrc(pGU), rGX = make_rsrc(pGX);
+            const i32x4 rGU = srd_uniform(pGU);
+            const rsrc_t rGX = make_rsrc(pGX);
             static_for<0, DEPTH>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 wait_bslot<(DEPTH - 1 - i) * NLD>(ring[i]);
@@ -295,10 +316,10 @@ extern "C" int dmn_sru_bwd(const float *U, const float *x, const float *bias, co
     // tuning / test hook: DMN_SRU_BWD_DEPTH=<n> forces the ring depth (read on every call)
     const char *env = getenv("DMN_SRU_BWD_DEPTH");
     int depth = env ? atoi(env) : 0;
-    // measured (tools/sru_bwd_bench.py, T = 2000, 64 320 columns): depth 3 runs 72.5 % (k = 3) / 72.2 % (k = 4)
-    // of 8 TB/s, depth 2 65 %, depths 4-16 68-69 % / 71-72 %: the launch is HBM-bound and a deeper ring
-    // only adds rows that compete in the memory system
-    if (depth <= 0) depth = 3;
+    // measured (tools/sru_bwd_bench.py, T = 2000, 64 320 columns): depth 4 runs 73.1 % (k = 3) / 72.6 % (k = 4)
+    // of 8 TB/s, depth 3 68-69 %, depth 2 54-59 %, depths 6-16 68-69 % / 71 %: the launch is HBM-bound and a
+    // deeper ring only adds rows that compete in the memory system
+    if (depth <= 0) depth = 4;
 #define DMN_BWD_K(KV)                                                                                                                             \
     do {                                                                                                                                          \
         if (depth <= 2) launch_bwd_act<KV, 2>(act, grid, s, U, x, bias, c0, c_all, grad_h, grad_last, grad_U, grad_x, grad_bias, grad_c0, T, ncols, d, scale_x);        \

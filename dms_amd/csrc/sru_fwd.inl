@@ -93,7 +93,8 @@ __device__ __forceinline__ float scan_range(ScanPtrs &p, unsigned strideU, unsig
                                             float bf2, float br2, float sx)
 {
     constexpr int NLD = (K == 3) ? 2 : 1;                       // VMEM loads per step
-    constexpr int NST = (STORE_H ? 1 : 0) + (STORE_C ? 1 : 0);  // VMEM stores per step
+    // VMEM stores per step that a wait may leave outstanding: none (sru_ring.h, DMN_VMCNT_COUNT_STORES)
+    constexpr int NST = DMN_VMCNT_COUNT_STORES ? ((STORE_H ? 1 : 0) + (STORE_C ? 1 : 0)) : 0;
     Slot<K> ring[DEPTH] = {};
     const ScanPtrs start = p;
 

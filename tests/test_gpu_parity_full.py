@@ -353,3 +353,53 @@ def test_left_padded_query_batch_through_hip_language_sru_equals_batch1_runs_bit
     with torch.no_grad():
         hr, _ = ref(we[:, 3:4].cpu())
     assert rel_err(h[:, 3:4].cpu(), hr) < 1e-5
+
+
+# ------------------------------------------------------------------------------------
+# configs[3]: the training step's scans at their real size
+# ------------------------------------------------------------------------------------
+@pytest.mark.parametrize("k", [3, 4])
+def test_config4_training_scans_T2000_B64_d1005_forward_with_c_and_backward_column_subset_oracle(k):
+    """mSRU of the 320 px training step: T = 100 pixels x 20 words, B = 64, d = 1005 (64 320 columns =
+    1005 wavefronts, one per SIMD: the occupancy and memory latencies the small-shape tests never
+    see).  Forward with the per-step c store, then the backward scan, on columns spread over the
+    batch vs the CPU oracle run on those columns alone; grad_bias vs the sum of the oracle's
+    per-column terms over a whole j-class."""
+    T, B, d = 2000, 64, 1005
+    gen = torch.Generator(device=DEV).manual_seed(2222 + k)
+    u = torch.randn((T, B, d, k), device=DEV, generator=gen)
+    x = torch.randn((T, B, d), device=DEV, generator=gen) if k == 3 else None
+    bias = 0.1 * torch.randn((2 * d,), device=DEV, generator=gen)
+    c0 = torch.randn((B, d), device=DEV, generator=gen)
+    gh = torch.randn((T, B, d), device=DEV, generator=gen)
+    gl = torch.randn((B, d), device=DEV, generator=gen)
+    ug, bg, cg = u.clone().requires_grad_(True), bias.clone().requires_grad_(True), c0.clone().requires_grad_(True)
+    xg = x.clone().requires_grad_(True) if x is not None else None
+    h, c_last = ops.sru_compute(ug, xg, bg, cg, "tanh", 1.0)
+    ((h * gh).sum() + (c_last * gl).sum()).backward()
+    assert all(bool(torch.isfinite(t.grad).all()) for t in (ug, bg, cg))
+    # columns: first / last of wavefronts, sample boundaries, and ALL 64 samples of column j = 17
+    jcls = torch.arange(B) * d + 17
+    cols = torch.cat([torch.tensor([0, 63, 64, 1004, 1005, 32159, 32160, B * d - 64, B * d - 1]), jcls])
+    cd = cols.to(DEV)
+    n = len(cols)
+    us = u.view(T, B * d, k)[:, cd].cpu().contiguous().view(T, 1, n, k)
+    xs = x.view(T, B * d)[:, cd].cpu().contiguous().view(T, 1, n) if x is not None else None
+    bj = torch.cat([bias[:d].cpu()[cols % d], bias[d:].cpu()[cols % d]])
+    c0s = c0.view(B * d)[cd].cpu().view(1, n)
+    ghs = gh.view(T, B * d)[:, cd].cpu().contiguous().view(T, 1, n)
+    gls = gl.view(B * d)[cd].cpu().view(1, n)
+    xn = None if xs is None else xs.numpy()
+    h_ref, c_ref, cl_ref = sru_ref.sru_fwd_c(us.numpy(), xn, bj.numpy(), c0s.numpy(), "tanh", 1.0)
+    np.testing.assert_allclose(h.detach().view(T, B * d)[:, cd].cpu().numpy(), h_ref[:, 0], rtol=1e-4, atol=3e-6)
+    np.testing.assert_allclose(c_last.detach().view(B * d)[cd].cpu().numpy(), cl_ref[0], rtol=1e-4, atol=3e-6)
+    gu_r, gx_r, gb_r, gc0_r = sru_ref.sru_bwd_c(us.numpy(), xn, bj.numpy(), c0s.numpy(), c_ref, ghs.numpy(),
+                                                gls.numpy(), "tanh", 1.0)
+    np.testing.assert_allclose(ug.grad.view(T, B * d, k)[:, cd].cpu().numpy(), gu_r[:, 0], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(cg.grad.view(B * d)[cd].cpu().numpy(), gc0_r[0], rtol=2e-4, atol=2e-5)
+    if x is not None:
+        np.testing.assert_allclose(xg.grad.view(T, B * d)[:, cd].cpu().numpy(), gx_r[:, 0], rtol=2e-4, atol=2e-5)
+    # in-kernel batch reduction: grad_bias[17] and grad_bias[d + 17] = sums over the 64 samples
+    want_b = gb_r[:, 0, 9:].sum(axis=1)
+    got_b = torch.stack([bg.grad[17], bg.grad[d + 17]]).cpu().numpy()
+    np.testing.assert_allclose(got_b, want_b, rtol=5e-4, atol=1e-3)

@@ -10,7 +10,7 @@ from dms_amd import ops
 dev = "cuda"
 
 
-def run(T, B, d, k, h_t0, nch, depth, iters=10):
+def run(T, B, d, k, h_t0, nch, depth, iters=10, want_c=False):
     if depth:
         os.environ["DMN_SRU_DEPTH"] = str(depth)
     else:
@@ -20,16 +20,16 @@ def run(T, B, d, k, h_t0, nch, depth, iters=10):
     x = torch.randn((T, B, d), device=dev, generator=g) if k == 3 else None
     bias = 0.1 * torch.randn((2 * d,), device=dev, generator=g)
     for _ in range(2):
-        ops.sru_forward_raw(u, x, bias, None, "tanh", 1.0, h_t0, want_c=False, nchunks=nch)
+        ops.sru_forward_raw(u, x, bias, None, "tanh", 1.0, h_t0, want_c=want_c, nchunks=nch)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(iters):
-        ops.sru_forward_raw(u, x, bias, None, "tanh", 1.0, h_t0, want_c=False, nchunks=nch)
+        ops.sru_forward_raw(u, x, bias, None, "tanh", 1.0, h_t0, want_c=want_c, nchunks=nch)
     b.record()
     torch.cuda.synchronize()
     ms = a.elapsed_time(b) / iters
-    nbytes = (4 * k + (4 if k == 3 else 0)) * T * B * d + 4 * (T - h_t0) * B * d
-    print("T=%5d B=%3d d=%4d k=%d h_t0=%5d nch=%2d depth=%2s : %8.3f ms  %7.1f GB/s (%.1f%% of 8 TB/s)"
+    nbytes = (4 * k + (4 if k == 3 else 0)) * T * B * d + 4 * (T - h_t0) * B * d + (4 * T * B * d if want_c else 0)
+    print(("+c " if want_c else "") + "T=%5d B=%3d d=%4d k=%d h_t0=%5d nch=%2d depth=%2s : %8.3f ms  %7.1f GB/s (%.1f%% of 8 TB/s)"
           % (T, B, d, k, h_t0, nch, depth or "-", ms, nbytes / ms / 1e6, nbytes / ms / 1e6 / 80), flush=True)
 
 
@@ -98,6 +98,19 @@ if __name__ == "__main__":
                 run(5120, B, 1005, 3, 0, 1, depth)
         for depth in (3, 4, 6, 8, 16, 32):
             run_state(4864, 32, 1005, depth)
+    if which == "depth2":     # stores left out of the counted waits (DMN_VMCNT_COUNT_STORES = 0): re-tune
+        for k in (3, 4):
+            for depth in (8, 16, 24, 32):
+                run(5120, 32, 1005, k, 0, 1, depth)
+        for k in (3, 4):
+            for depth in (4, 6, 8, 16, 24):
+                run(2000, 64, 1005, k, 0, 1, depth, want_c=True)
+        for depth in (4, 6, 8, 16):
+            run(5120, 64, 1005, 3, 0, 1, depth)
+        for depth in (16, 24, 32):
+            run(5120, 16, 1005, 3, 0, 1, depth)
+        for depth in (3, 4, 6):
+            run(4096, 128, 1000, 3, 0, 1, depth)
     if which == "policy":
         run(5120, 32, 1005, 4, 0, 1, 32)
         run(5120, 32, 1005, 3, 0, 1, 32)
