@@ -344,6 +344,16 @@ def run_train320(args, device, rank, world, timer):
                       file=sys.stderr, flush=True)
 
     threading.Thread(target=heartbeat, daemon=True).start()
+    # watchdog: a step that exceeds its limit dumps every thread's Python stack to stderr and exits
+    # non-zero, so a hung exchange names itself instead of running into the launcher's time limit.
+    # DMN_BENCH_WATCHDOG="first,later" in seconds (the first step includes the MIOpen find phase)
+    import faulthandler
+    wd_first, wd_later = [float(v) for v in os.environ.get("DMN_BENCH_WATCHDOG", "900,240").split(",")]
+
+    def arm(limit):
+        faulthandler.cancel_dump_traceback_later()
+        if limit > 0:
+            faulthandler.dump_traceback_later(limit, exit=True)
     os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")          # bound the find phase (heuristic pick, no exhaustive search)
     net = build_model(device, high_res=False).train()
     opt = torch.optim.Adam(net.parameters(), lr=1e-5)
@@ -380,10 +390,12 @@ def run_train320(args, device, rank, world, timer):
     for i in range(args.warmup):
         phase["name"] = "warm-up step %d (MIOpen find / kernel compilation on the first one)" % i
         print("[train320] rank %d starting warm-up step %d" % (rank, i), file=sys.stderr, flush=True)
+        arm(wd_first if i == 0 else wd_later)
         loss = step()
         torch.cuda.synchronize()
         print("[train320] rank %d warm-up step %d done" % (rank, i), file=sys.stderr, flush=True)
     phase["name"] = "timed steps"
+    arm((wd_later * args.steps) if args.warmup else (wd_first + wd_later * args.steps))
     if world > 1:
         dist.barrier()
     timer.records, ar_ms[:] = [], []
@@ -399,6 +411,7 @@ def run_train320(args, device, rank, world, timer):
     elapsed = time.perf_counter() - t0
     timer.enabled = False
     phase["stop"] = True
+    arm(0)
     assert bool(torch.isfinite(loss))
     el = torch.tensor([elapsed], dtype=torch.float64,
                       device=device if dist.is_initialized() and dist.get_backend() == "nccl" else "cpu")

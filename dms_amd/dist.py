@@ -10,9 +10,13 @@ an autograd hook as soon as its last gradient has been written, so the exchange 
 of backward (``allreduce_gradients`` is the simple after-backward form).
 """
 import os
+import sys
 
 import torch
 import torch.distributed as dist
+
+
+_DEBUG = bool(os.environ.get("DMN_REDUCER_DEBUG"))     # trace finish() bucket by bucket on stderr
 
 
 def init_from_env(backend=None):
@@ -58,6 +62,8 @@ class OverlappedGradReducer(object):
     Use ``reducer.zero_grad()`` instead of ``optimizer.zero_grad(set_to_none=True)``, which would
     drop the views.  Without a process group (or world size 1) everything degrades to plain
     local gradients.  ``launch_log`` records (bucket index, launched_during_backward) per step.
+    With backend gloo and device buckets the exchange is staged through pinned host memory (see
+    ``_staged`` below): the copies overlap backward, the host all-reduce runs in ``finish()``.
     """
 
     def __init__(self, params, bucket_mb=128, average=True, group=None):
@@ -91,17 +97,38 @@ class OverlappedGradReducer(object):
         self._work = [None] * len(self.buckets)
         self._in_backward = True
         self.launch_log = []
+        # backend gloo + buckets in device memory (the one-GPU rehearsal of the N > 1 path): the exchange
+        # is staged through pinned host memory by the reducer itself.  gloo's own device-tensor path
+        # hung on the MI355X box in the second training step -- both ranks inside wait() of the first
+        # bucket, same launch order on both (profiles/r2_train320_2rank_gloo.md) -- and host tensors are
+        # what gloo reduces anyway.  RCCL ("nccl") reduces the device buckets in place.
+        self._staged = (self.world > 1 and self.buckets and self.buckets[0].is_cuda
+                        and dist.get_backend(group) == "gloo")
+        if self._staged:
+            self._side = torch.cuda.Stream(device=self.buckets[0].device)
+            self._host = [torch.empty(b.numel(), dtype=b.dtype, pin_memory=True) for b in self.buckets]
         self._handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
 
     def _launch(self, bi):
         if self._work[bi] is not None:
             return
         self.launch_log.append((bi, self._in_backward))
-        if self.world > 1:
+        if self.world <= 1:
+            self._work[bi] = True
+        elif self._staged:
+            # gloo with device buckets: start the bucket's copy to pinned host memory on the side
+            # stream now (it overlaps the rest of backward); the host all-reduce runs in finish()
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(ev)
+                self._host[bi].copy_(self.buckets[bi], non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(self._side)
+            self._work[bi] = done
+        else:
             self._work[bi] = dist.all_reduce(self.buckets[bi], op=dist.ReduceOp.SUM, group=self.group,
                                              async_op=True)
-        else:
-            self._work[bi] = True
 
     def _hook(self, p):
         bi = self._bucket_of[p]
@@ -122,11 +149,29 @@ class OverlappedGradReducer(object):
         self._in_backward = False
         for bi in range(len(self.buckets)):
             self._launch(bi)
-        for bi, w in enumerate(self._work):
-            if w is not True:
+        if self._staged and self.world > 1:
+            works = []
+            for bi, done in enumerate(self._work):
+                done.synchronize()                                   # the bucket is in host memory
+                works.append(dist.all_reduce(self._host[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            for bi, w in enumerate(works):
+                if _DEBUG:
+                    print("[reducer] rank %d waiting for host bucket %d of %d" % (dist.get_rank(self.group), bi, len(works)),
+                          file=sys.stderr, flush=True)
                 w.wait()
-            if self.average and self.world > 1:
-                self.buckets[bi].div_(self.world)
+                self.buckets[bi].copy_(self._host[bi], non_blocking=True)
+                if self.average:
+                    self.buckets[bi].div_(self.world)
+        else:
+            for bi, w in enumerate(self._work):
+                if w is not True:
+                    if _DEBUG:
+                        print("[reducer] rank %d waiting for bucket %d of %d (launch order %s)" % (
+                            dist.get_rank(self.group), bi, len(self._work), [b for b, _ in self.launch_log[-len(self._work):]]),
+                            file=sys.stderr, flush=True)
+                    w.wait()
+                if self.average and self.world > 1:
+                    self.buckets[bi].div_(self.world)
         calls = len(self._work)
         self._arrived = [0] * len(self.buckets)
         self._work = [None] * len(self.buckets)
