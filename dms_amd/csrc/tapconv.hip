@@ -121,7 +121,7 @@ tap_gather_kernel(const float *__restrict__ Z, const float *__restrict__ bias, f
 }
 
 // ------------------------------------------------------------------------------------------------
-// Tiled variant for power-of-two widths W = 16 .. 128 (the four wide head levels), round 2.
+// Tiled variant for power-of-two widths W = 16 .. 256 (all five head levels at 512 px), round 2.
 // The sweep kernel above spends 71 % of its wave cycles in s_waitcnt (rocprofv3 SQ_WAIT_ANY) with the
 // VALU 5 % busy: every lane walks its rows one memory round trip at a time, three loads per tap (8-byte
 // + two neighbour dwords), 94 VGPRs.  Here a 256-thread workgroup takes a BAND of 1024 consecutive
@@ -133,7 +133,7 @@ tap_gather_kernel(const float *__restrict__ Z, const float *__restrict__ bias, f
 // the 2 x 8 outputs of its four columns.  When a plane is taller than a band, lanes 0 .. W/2-1 also
 // fetch the band's two halo rows; consecutive bands are mapped to the SAME XCD (workgroups are dealt to
 // the 8 XCDs round-robin), so that those re-reads are L2 hits.
-template <int W>
+template <int W, int LM>
 __global__ void __launch_bounds__(256)
 tap_gather_tile_kernel(const float *__restrict__ Z, const float *__restrict__ bias, float *__restrict__ out,
                        int Cout, int H, long long out_bs, int nbands, int total, int xcd_chunk)
@@ -150,12 +150,26 @@ tap_gather_tile_kernel(const float *__restrict__ Z, const float *__restrict__ bi
     const int R0 = band * NR;
 
     // horizontal pass of one low-res row segment: h[ky][c] = sum_kx upx(z[ky*3+kx])[2*c0 + c + kx - 1]
-    auto hpass = [&](long long R, int c0, float (&h)[3][8]) {
+    auto hpass = [&](long long R, int c0, float (&h)[3][8], bool keep) {
         const float *zr = zb + R * W + c0;
         f32x4_t z[9];
+        if (LM == 1) {
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
-            z[tap] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(zr + tap * tapstride));
+            for (int tap = 0; tap < 9; ++tap)
+                z[tap] = *reinterpret_cast<const f32x4_t *>(zr + tap * tapstride);
+        } else if (LM == 2 && keep) {
+            // rows that a neighbouring band reads again as halo stay in L2 (plain loads); the empty asm keeps
+            // hipcc from merging this branch with the streamed one below (the merge drops the nt hint)
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+                z[tap] = *reinterpret_cast<const f32x4_t *>(zr + tap * tapstride);
+            asm volatile("" ::: "memory");
+        } else {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+                z[tap] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(zr + tap * tapstride));
+        }
         const bool el = c0 == 0, er = c0 + 4 == W;           // row edges: clamp (bilinear) and zero (conv pad)
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
@@ -192,7 +206,7 @@ tap_gather_tile_kernel(const float *__restrict__ Z, const float *__restrict__ bi
     const long long R = (long long)R0 + rr;
     const int co = (int)(R / H), r = (int)(R - (long long)co * H);
     float Rc[3][8];
-    hpass(R, c0, Rc);
+    hpass(R, c0, Rc, H > NR && (rr == 0 || rr == NR - 1));
     put(rr + 1, c0, Rc);
     if (H > NR && t < 2 * LPR) {                              // halo rows (same plane only)
         const int bottom = t / LPR;
@@ -200,7 +214,7 @@ tap_gather_tile_kernel(const float *__restrict__ Z, const float *__restrict__ bi
         const int rfirst = (int)((long long)R0 % H);          // row of the band's first line inside its plane
         if (bottom ? (rfirst + NR < H) : (rfirst > 0)) {
             float Rh3[3][8];
-            hpass(Rh, c0, Rh3);
+            hpass(Rh, c0, Rh3, true);
             put(bottom ? NR + 1 : 0, c0, Rh3);
         }
     }
@@ -233,10 +247,15 @@ tap_gather_tile_kernel(const float *__restrict__ Z, const float *__restrict__ bi
     }
     float *p0 = out + (long long)b * out_bs + ((long long)co * 2 * H + 2 * r) * W2 + 2 * c0;   // plane = (2H) x (2W)
     float *p1 = p0 + W2;
-    store_stream4(p0, o0[0], o0[1], o0[2], o0[3]);
-    store_stream4(p0 + 4, o0[4], o0[5], o0[6], o0[7]);
-    store_stream4(p1, o1[0], o1[1], o1[2], o1[3]);
-    store_stream4(p1 + 4, o1[4], o1[5], o1[6], o1[7]);
+    // plain (write-back) stores: a lane owns 32 contiguous bytes of each output row and writes them as two
+    // 16-byte pieces, so one store instruction covers only half of every 32-byte sector.  As streamed
+    // (non-temporal) stores those half-written lines left L2 in pieces: WRITE_SIZE +13 .. +17 % over the
+    // output bytes and 5.2-5.4 TB/s; left to merge in L2 the traffic is exact (+0.0 %) and the three
+    // smaller levels run at 5.9-6.1 TB/s (tools/tap_store_modes.sh, profiles/r2_tap_store_modes.txt)
+    *reinterpret_cast<float4 *>(p0) = make_float4(o0[0], o0[1], o0[2], o0[3]);
+    *reinterpret_cast<float4 *>(p0 + 4) = make_float4(o0[4], o0[5], o0[6], o0[7]);
+    *reinterpret_cast<float4 *>(p1) = make_float4(o1[0], o1[1], o1[2], o1[3]);
+    *reinterpret_cast<float4 *>(p1 + 4) = make_float4(o1[4], o1[5], o1[6], o1[7]);
 }
 
 // Z[b, r, p] = sum_c w[r, c] * in[b, c, p], r = 0..8, in = cat(x, feat) over channels (never built).
@@ -299,11 +318,11 @@ extern "C" int dmn_tap_upsample_gather(const float *Z, const float *bias, float 
     if ((long long)B * Cout >= (1LL << 31) / 4)
         return fail(-5, "dmn_tap_upsample_gather: B*Cout=%lld too large", (long long)B * Cout);
     hipStream_t s = (hipStream_t)stream;
-    // tiled kernel: power-of-two widths 16 .. 128, bands of 1024 / W rows that tile the (co, row) slab
+    // tiled kernel: power-of-two widths 16 .. 256, bands of 1024 / W rows that tile the (co, row) slab
     // and either hold whole planes or divide one (DMN_TAP_TILE=0: the sweep kernel, for A/B runs)
     {
         const char *te = getenv("DMN_TAP_TILE");
-        const bool wok = W == 16 || W == 32 || W == 64 || W == 128;
+        const bool wok = W == 16 || W == 32 || W == 64 || W == 128 || W == 256;
         const int NR = wok ? 1024 / W : 1;
         if (wok && !(te && atoi(te) == 0) && ((long long)Cout * H) % NR == 0 && (H % NR == 0 || NR % H == 0)
             && !(((uintptr_t)Z | (uintptr_t)out) & 15) && (long long)B * Cout * H / NR < (1LL << 30)) {
@@ -311,11 +330,19 @@ extern "C" int dmn_tap_upsample_gather(const float *Z, const float *bias, float 
             const int total = B * nbands;
             const int xcd_chunk = (total + 7) / 8;
             dim3 tgrid((unsigned)xcd_chunk * 8);
-#define DMN_TILE(WV) hipLaunchKernelGGL(tap_gather_tile_kernel<WV>, tgrid, dim3(256), 0, s, Z, bias, out, Cout, H, out_bs, nbands, total, xcd_chunk)
+            // load policy (tools/tap_store_modes.sh, profiles/r2_tap_store_modes.txt): streamed loads, except the
+            // rows a neighbouring band reads again as halo (2); W = 16 (whole planes per band, 36 KiB per tap
+            // set) runs 13 % faster with plain loads (1).  DMN_TAP_LOAD=0|1|2 forces one for A/B runs.
+            const char *se = getenv("DMN_TAP_LOAD");
+            const int sm = se ? atoi(se) : (W == 16 ? 1 : 2);
+#define DMN_TILE2(WV, SMV) hipLaunchKernelGGL((tap_gather_tile_kernel<WV, SMV>), tgrid, dim3(256), 0, s, Z, bias, out, Cout, H, out_bs, nbands, total, xcd_chunk)
+#define DMN_TILE(WV) do { if (sm == 0) DMN_TILE2(WV, 0); else if (sm == 1) DMN_TILE2(WV, 1); else DMN_TILE2(WV, 2); } while (0)
             if (W == 16) DMN_TILE(16);
             else if (W == 32) DMN_TILE(32);
             else if (W == 64) DMN_TILE(64);
-            else DMN_TILE(128);
+            else if (W == 128) DMN_TILE(128);
+            else DMN_TILE(256);
+#undef DMN_TILE2
 #undef DMN_TILE
             return launch_status("dmn_tap_upsample_gather");
         }

@@ -1,0 +1,72 @@
+"""GPU test (-m gpu): the N > 1 training exchange with DEVICE buckets, world size 2 on one card.
+RCCL refuses two ranks on one device, so the backend is gloo and OverlappedGradReducer stages the
+buckets through pinned host memory (dms_amd/dist.py, `_staged`) -- the path bench.py's one-GPU
+rehearsal of --workload train320 takes (profiles/r2_train320_2rank_gloo.md)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from dms_amd.dist import OverlappedGradReducer, shard_range
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _toy():
+    torch.manual_seed(0)
+    return torch.nn.Sequential(torch.nn.Linear(64, 300), torch.nn.Tanh(), torch.nn.Linear(300, 200), torch.nn.Tanh(),
+                               torch.nn.Linear(200, 1))
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda", 0)
+        model = _toy().to(dev)
+        red = OverlappedGradReducer(list(model.parameters()), bucket_mb=0.1, average=True)
+        assert red._staged and len(red.buckets) >= 3
+        x = (torch.arange(16 * 64, dtype=torch.float32).view(16, 64) % 13 - 6.0) / 10.0
+        lo, hi = shard_range(16, rank, world)
+        steps = []
+        for step in range(3):                                     # the gloo device path hung on the SECOND step
+            red.zero_grad()
+            red.launch_log = []
+            loss = model(x[lo:hi].to(dev) * (step + 1)).pow(2).sum() / (hi - lo)
+            loss.backward()
+            in_bwd = list(red.launch_log)
+            calls = red.finish()
+            torch.cuda.synchronize()
+            steps.append({"grad": torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu(),
+                          "calls": calls, "in_bwd": in_bwd})
+        if rank == 0:
+            torch.save(steps, out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(240)
+def test_device_buckets_over_gloo_world2_three_steps_equal_the_single_process_gradient(tmp_path):
+    assert torch.cuda.is_available(), "this test needs a real MI355X"
+    out = str(tmp_path / "g.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    steps = torch.load(out)
+    x = (torch.arange(16 * 64, dtype=torch.float32).view(16, 64) % 13 - 6.0) / 10.0
+    for step, got in enumerate(steps):
+        model = _toy()
+        model(x * (step + 1)).pow(2).mean().backward()
+        ref = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+        torch.testing.assert_close(got["grad"], ref, rtol=2e-5, atol=1e-6)
+        assert got["calls"] == len(got["in_bwd"]) >= 3
+        assert all(inb for _, inb in got["in_bwd"])               # every bucket's copy started from a hook

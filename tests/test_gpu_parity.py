@@ -527,7 +527,9 @@ def test_head_final_equals_conv_then_out_layer(B, Cx, Cf, H, W, Co):
                                               # (H <= 1024 / W), bands with halo rows (H > 1024 / W), non-square
                                               (1, 3, 2, 32, 32, 4), (1, 2, 2, 64, 64, 2), (1, 1, 1, 128, 128, 2),
                                               (2, 2, 1, 8, 32, 4), (1, 2, 2, 32, 64, 3), (1, 2, 1, 128, 16, 2),
-                                              (2, 3, 1, 16, 128, 3)])
+                                              (2, 3, 1, 16, 128, 3),
+                                              # W = 256: bands of 4 rows, one row per wavefront (the last head level)
+                                              (1, 2, 1, 256, 256, 1), (2, 1, 2, 8, 256, 3), (1, 1, 1, 4, 256, 2)])
 def test_tap_gemm_level_matches_cat_upsample_conv(B, Cx, Cf, H, W, Cout, monkeypatch):
     """nine tap matrices at low resolution (library GEMM) + gather at high resolution ==
     conv3x3(upsample2x(cat)) (dmn.py:324,337-338), incl. odd sizes, 1-pixel maps, empty sources."""
