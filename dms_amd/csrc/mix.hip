@@ -181,6 +181,124 @@ mix_bwd_pix_kernel(const float *__restrict__ gQ, const float *__restrict__ Wp, i
     }
 }
 
+// ---- backward A, round 2: same outputs, no LDS traffic in the inner loop -------------------------------
+// mix_bwd_pix_kernel reads its K filter columns from LDS for every 16 bytes of gQ (40 ds_read_b128 per
+// word and lane) and reduces every (t, k) dot product with its own 6-step butterfly (300 cross-lane
+// operations per pixel and wave): 0.62 ms for the 512 MB of gQ at the training size, 10 % of HBM.  Here a
+// lane keeps the K <= 10 filter weights of its 8 columns in 80 registers (512-thread workgroups: waves 0-3 take
+// columns < 512, waves 4-7 the rest, so that two waves fit a SIMD) for the whole workgroup
+// (PT pixels, unrolled), a pixel's rows are loaded while the previous pixel's are consumed, and the wave's
+// NW * 10 <= 64 partial dot products are reduced TOGETHER by a transposing butterfly (step o: a lane keeps
+// the half of the list its bit o selects and adds the partner's copy of it; 32 + 16 + .. + 1 = 63
+// exchanges, after which lane l holds the wave total of value l).  Requires K <= 10, L <= 24, M % 4 == 0,
+// M <= 1024.
+constexpr int MIX_BWD2_K = 10, MIX_BWD2_NW = 6;
+
+template <int NW, int PT>
+__global__ void __launch_bounds__(512)
+mix_bwd_pix2_kernel(const float *__restrict__ gQ, const float *__restrict__ Wp, int ldw,
+                    float *__restrict__ gA, float *__restrict__ gP, int B, int L, int K, int S, int M)
+{
+    constexpr int KR = MIX_BWD2_K;
+    extern __shared__ float lds2[];                 // Wl[KR][1024] while the weights are fetched, then ga_lds[4][M] + red[4][64]
+    const int b = blockIdx.y, s0 = blockIdx.x * PT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wq = wave & 3, half = wave >> 2;      // word group / column half (m < 512 or >= 512)
+    // the K filter columns: one pass over Wp's rows (K contiguous floats each), transposed through LDS so
+    // that a lane's 4 adjacent columns are one ds_read_b128 per filter
+    for (int idx = threadIdx.x; idx < KR * 1024; idx += 512) {
+        const int m = idx / KR, k = idx - m * KR;
+        lds2[k * 1024 + m] = (m < M && k < K) ? Wp[(long long)m * ldw + k] : 0.0f;
+    }
+    __syncthreads();
+    const int mbase = half * 512 + lane * 4;        // this lane's columns: mbase + 256 * i + {0..3}, i = 0, 1
+    float w[2][4][KR];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {
+            const float4 wv = *reinterpret_cast<const float4 *>(lds2 + k * 1024 + mbase + 256 * i);
+            w[i][0][k] = wv.x; w[i][1][k] = wv.y; w[i][2][k] = wv.z; w[i][3][k] = wv.w;
+        }
+    float *ga_lds = lds2, *red = lds2 + 4 * 1024;   // reused after the barrier below
+
+    // rows of pixel s that this wave owns (words wq, wq+4, ..); rows past L / S / M read as zero
+    f32x4_t g[NW][2];
+    auto load_word = [&](int s, int tt) {
+        const int t = wq + 4 * tt;
+        const bool ok = t < L && s < S;
+        const float *gr = gQ + (((long long)(ok ? s : 0) * L + (ok ? t : 0)) * B + b) * M;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = mbase + 256 * i;
+            g[tt][i] = (ok && m < M) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(gr + m))
+                                     : (f32x4_t){0.0f, 0.0f, 0.0f, 0.0f};
+        }
+    };
+#pragma unroll
+    for (int tt = 0; tt < NW; ++tt) load_word(s0, tt);
+    __syncthreads();                                // every lane has its weights: Wl may be overwritten
+
+#pragma unroll
+    for (int pp = 0; pp < PT; ++pp) {
+        const int s = s0 + pp;
+        float ga[8], v[64];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ga[i] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 64; ++i) v[i] = 0.0f;
+#pragma unroll
+        for (int tt = 0; tt < NW; ++tt) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float ge[4] = {g[tt][i].x, g[tt][i].y, g[tt][i].z, g[tt][i].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ga[i * 4 + e] += ge[e];
+#pragma unroll
+                    for (int k = 0; k < KR; ++k)
+                        v[tt * KR + k] = __builtin_fmaf(w[i][e][k], ge[e], v[tt * KR + k]);
+                }
+            }
+            if (pp + 1 < PT) load_word(s + 1, tt);  // the next pixel's row into the registers just consumed
+        }
+        // transposing butterfly: 64 values x 64 lanes -> lane l holds the wave's total of value l
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const bool up = lane & o;
+#pragma unroll
+            for (int jx = 0; jx < o; ++jx) {
+                const float send = up ? v[jx] : v[jx + o];
+                const float keep = up ? v[jx + o] : v[jx];
+                v[jx] = keep + __shfl_xor(send, o, 64);
+            }
+        }
+        if (pp > 0) __syncthreads();                // previous pixel's ga_lds / red readers are done
+        if (half == 1) red[wq * 64 + lane] = v[0];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = mbase + 256 * i;
+            if (m < M)
+                *reinterpret_cast<float4 *>(ga_lds + wq * 1024 + m) =
+                    make_float4(ga[i * 4], ga[i * 4 + 1], ga[i * 4 + 2], ga[i * 4 + 3]);
+        }
+        __syncthreads();
+        if (s < S) {                                // uniform
+            if (half == 0) {
+                const int tt = lane / KR, k = lane - tt * KR, t = wq + 4 * tt;
+                if (tt < NW && t < L && k < K) gP[lbk_off(t, b, k, B, K, S) + s] = v[0] + red[wq * 64 + lane];
+            }
+            for (int m = threadIdx.x * 4; m < M; m += 2048) {
+                const float4 a0 = *reinterpret_cast<const float4 *>(ga_lds + m), a1 = *reinterpret_cast<const float4 *>(ga_lds + 1024 + m);
+                const float4 a2 = *reinterpret_cast<const float4 *>(ga_lds + 2048 + m), a3 = *reinterpret_cast<const float4 *>(ga_lds + 3072 + m);
+                *reinterpret_cast<float4 *>(gA + ((long long)b * S + s) * M + m) =
+                    make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y),
+                                (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w));
+            }
+        }
+    }
+}
+
 // ---- backward B: per (t, b): gBt[t,b,m] = sum_s gQ ; gWp_part[t,b,m,k] = sum_s gQ * P ----
 // One workgroup per (t, b); a lane owns 4 adjacent m (16-byte loads), the pixel loop is
 // unrolled so that 4 independent rows are in flight per lane; P[t,b] (K x S) sits in LDS.
@@ -236,6 +354,63 @@ mix_bwd_word_kernel(const float *__restrict__ gQ, const float *__restrict__ P,
                 if (k < K) gWp_part[(((long long)t * B + b) * M + m + e) * K + k] = gw[e][k];
         }
     }
+}
+
+// ---- backward B, round 2: K <= 10 at compile time, P rows padded to 12 floats in LDS (three 16-byte
+// broadcast reads per pixel instead of up to 16 guarded 4-byte ones), five pixels in flight per lane ----
+template <int UNR>
+__global__ void __launch_bounds__(256)
+mix_bwd_word2_kernel(const float *__restrict__ gQ, const float *__restrict__ P,
+                     float *__restrict__ gBt, float *__restrict__ gWp_part,
+                     int B, int L, int K, int S, int M)
+{
+    constexpr int KR = MIX_BWD2_K, KP = 12;
+    extern __shared__ float Pt2[];           // [S][KP] for this (t, b), zero beyond K
+    const int t = blockIdx.x, b = blockIdx.y;
+    for (int idx = threadIdx.x; idx < KP * S; idx += blockDim.x) {
+        const int sp = idx / KP, k = idx - sp * KP;
+        Pt2[idx] = k < K ? P[lbk_off(t, b, k, B, K, S) + sp] : 0.0f;
+    }
+    __syncthreads();
+    const long long row_stride = (long long)L * B * M;     // between consecutive pixels
+    const int m = threadIdx.x * 4;
+    if (m >= M) return;
+    float gb[4] = {0.0f, 0.0f, 0.0f, 0.0f}, gw[4][KR];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int k = 0; k < KR; ++k) gw[e][k] = 0.0f;
+    const float *g0 = gQ + ((long long)t * B + b) * M + m;
+    auto step = [&](const f32x4_t gv, int sp) {
+        const float4 p0 = *reinterpret_cast<const float4 *>(Pt2 + sp * KP);
+        const float4 p1 = *reinterpret_cast<const float4 *>(Pt2 + sp * KP + 4);
+        const float2 p2 = *reinterpret_cast<const float2 *>(Pt2 + sp * KP + 8);
+        const float pv[KR] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x, p2.y};
+        const float ge[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            gb[e] += ge[e];
+#pragma unroll
+            for (int k = 0; k < KR; ++k) gw[e][k] = __builtin_fmaf(ge[e], pv[k], gw[e][k]);
+        }
+    };
+    int sp = 0;
+    for (; sp + UNR <= S; sp += UNR) {
+        f32x4_t gv[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+            gv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(g0 + (sp + u) * row_stride));
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) step(gv[u], sp + u);
+    }
+    for (; sp < S; ++sp)
+        step(__builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(g0 + sp * row_stride)), sp);
+    *reinterpret_cast<float4 *>(gBt + ((long long)t * B + b) * M + m) = make_float4(gb[0], gb[1], gb[2], gb[3]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int k = 0; k < KR; ++k)
+            if (k < K) gWp_part[(((long long)t * B + b) * M + m + e) * K + k] = gw[e][k];
 }
 
 static int check_mix(const char *fn, int B, int L, int K, int S, int M, int ldw)
@@ -298,9 +473,23 @@ extern "C" int dmn_mix_bcast_add_bwd(const float *gQ, const float *P, const floa
     if (lds > 64 * 1024) return fail(-5, "dmn_mix_bcast_add_bwd: K*S=%d too large for the LDS stage", K * S);
     hipStream_t s = (hipStream_t)stream;
     if (M % 4 != 0 || ((uintptr_t)gQ & 15)) return fail(-5, "dmn_mix_bcast_add_bwd: M %% 4 == 0 and 16-byte aligned gQ required");
-    const size_t lds_pix = (size_t)(K + 4) * M * sizeof(float);
-    hipLaunchKernelGGL(mix_bwd_pix_kernel, dim3((S + MIX_BWD_PT - 1) / MIX_BWD_PT, B), dim3(256), lds_pix, s, gQ, Wp, ldw, gA, gP, B, L, K, S, M);
-    if ((M % 4 == 0) && !((uintptr_t)gQ & 15))
+    const int nw = (L + 3) / 4;
+    const char *pe = getenv("DMN_MIX_BWD_PIX2");
+    if (K <= MIX_BWD2_K && nw <= MIX_BWD2_NW && !(((uintptr_t)gA) & 15) && !(pe && atoi(pe) == 0)) {
+        // pixels per workgroup: 5 when that divides S (S = 100 in training: 20 x B workgroups), else 4
+        const size_t lds2 = (size_t)MIX_BWD2_K * 1024 * sizeof(float);
+#define DMN_PIX2(NWV, PTV) hipLaunchKernelGGL((mix_bwd_pix2_kernel<NWV, PTV>), dim3((S + PTV - 1) / PTV, B), dim3(512), lds2, s, gQ, Wp, ldw, gA, gP, B, L, K, S, M)
+        if (S % 5 == 0) { if (nw <= 5) DMN_PIX2(5, 5); else DMN_PIX2(6, 5); }
+        else            { if (nw <= 5) DMN_PIX2(5, 4); else DMN_PIX2(6, 4); }
+#undef DMN_PIX2
+    } else {
+        const size_t lds_pix = (size_t)(K + 4) * M * sizeof(float);
+        hipLaunchKernelGGL(mix_bwd_pix_kernel, dim3((S + MIX_BWD_PT - 1) / MIX_BWD_PT, B), dim3(256), lds_pix, s, gQ, Wp, ldw, gA, gP, B, L, K, S, M);
+    }
+    const char *we = getenv("DMN_MIX_BWD_WORD2");
+    if (K <= MIX_BWD2_K && M <= 1024 && !((uintptr_t)gBt & 15) && !(we && atoi(we) == 0))
+        hipLaunchKernelGGL(mix_bwd_word2_kernel<5>, dim3(L, B), dim3(256), (size_t)12 * S * sizeof(float), s, gQ, P, gBt, gWp_part, B, L, K, S, M);
+    else if ((M % 4 == 0) && !((uintptr_t)gQ & 15))
         hipLaunchKernelGGL(mix_bwd_word_kernel<4>, dim3(L, B), dim3(256), lds, s, gQ, P, gBt, gWp_part, B, L, K, S, M);
     else
         hipLaunchKernelGGL(mix_bwd_word_kernel<1>, dim3(L, B), dim3(256), lds, s, gQ, P, gBt, gWp_part, B, L, K, S, M);

@@ -285,17 +285,32 @@ def test_mix_bcast_add_matches_einsum(B, L, K, S, M):
     assert rel_err(Q, ref) < 1e-5
 
 
-def test_mix_bcast_add_bwd_matches_autograd():
-    B, L, K, S, M = 2, 5, 3, 11, 24
+@pytest.mark.parametrize("B,L,K,S,M", [(2, 5, 3, 11, 24),          # small; wave 3 idle for L = 5? no: words 0..4 over 4 waves
+                                       (2, 20, 10, 100, 1000),     # the training shape per sample (configs[3])
+                                       (1, 24, 10, 7, 1024),       # six words per wave, full 1024 columns
+                                       (2, 3, 10, 5, 8),           # fewer words than waves, one active lane pair
+                                       (1, 21, 7, 3, 500),         # ragged word count, K < 10
+                                       (1, 25, 10, 4, 64),         # L > 24: the LDS-weight kernel
+                                       (2, 6, 12, 5, 40)])         # K > 10: the LDS-weight kernel
+def test_mix_bcast_add_bwd_matches_autograd(B, L, K, S, M, monkeypatch):
+    """gA, gBt, gP, gWp of the concat-free mix vs float64 autograd of its einsum restatement; the
+    register-weight pixel kernel (round 2) and the LDS-weight one must both pass and agree."""
     A, Bt = det_uniform((B, S, M), 111, 1.0), det_uniform((L, B, M), 112, 1.0)
     P, Wp = det_uniform((L, B, K, S), 113, 1.0), det_uniform((M, K), 114, 1.0)
     gQ = det_uniform((S * L, B, M), 115, 1.0)
-    gs = [t.to(DEV).requires_grad_(True) for t in (A, Bt, P, Wp)]
-    (ops.mix_bcast_add(*gs) * gQ.to(DEV)).sum().backward()
     rs = [t.clone().double().requires_grad_(True) for t in (A, Bt, P, Wp)]
     (_mix_ref(*rs) * gQ.double()).sum().backward()
-    for a, b, n in zip(gs, rs, "A Bt P Wp".split()):
-        assert rel_err(a.grad.cpu(), b.grad) < 1e-5, n
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("DMN_MIX_BWD_PIX2", mode)
+        monkeypatch.setenv("DMN_MIX_BWD_WORD2", mode)
+        gs = [t.to(DEV).requires_grad_(True) for t in (A, Bt, P, Wp)]
+        (ops.mix_bcast_add(*gs) * gQ.to(DEV)).sum().backward()
+        for a, b, n in zip(gs, rs, "A Bt P Wp".split()):
+            assert rel_err(a.grad.cpu(), b.grad) < 1e-5, (mode, n)
+        got[mode] = [a.grad.cpu() for a in gs]
+    for a, b, n in zip(got["1"], got["0"], "A Bt P Wp".split()):
+        assert rel_err(a, b) < 2e-6, n
 
 
 @pytest.mark.parametrize("B,Cx,Cf,H,W", [(2, 3, 5, 4, 6), (1, 7, 0, 3, 3), (1, 0, 4, 1, 1), (2, 2, 2, 5, 7),
