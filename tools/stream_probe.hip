@@ -50,6 +50,37 @@ __global__ void __launch_bounds__(64) rows41(const f32x4 *__restrict__ u, float 
     }
 }
 
+// 4 : 1 with WIDE stores: a thread takes 4 consecutive elements (4 float4 reads, ONE float4 write)
+template <bool NT>
+__global__ void __launch_bounds__(256) mix41_wide(const f32x4 *__restrict__ u, f32x4 *__restrict__ o, long long n4)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = NT ? __builtin_nontemporal_load(u + 4 * i + k) : u[4 * i + k];
+    f32x4 r;
+    r.x = (v[0].x + v[0].y) + (v[0].z + v[0].w); r.y = (v[1].x + v[1].y) + (v[1].z + v[1].w);
+    r.z = (v[2].x + v[2].y) + (v[2].z + v[2].w); r.w = (v[3].x + v[3].y) + (v[3].z + v[3].w);
+    if (NT) __builtin_nontemporal_store(r, o + i); else o[i] = r;
+}
+// 4 : 1, one element per thread but the 4-byte results of 4 neighbouring lanes gathered into one lane's
+// 16-byte store is not possible without a shuffle; instead: lane-strided reads so that stores are 16 B:
+// thread reads u[i], u[i + q], u[i + 2q], u[i + 3q] (q = n / 4) and writes 4 B to each quarter -> same as flat.
+
+// the backward scan's mix: read 24 B (a float4 + two floats), write 16 B per element
+template <bool NT>
+__global__ void __launch_bounds__(256) mix2416(const f32x4 *__restrict__ u, const float *__restrict__ a, const float *__restrict__ b2,
+                                                f32x4 *__restrict__ o, long long n)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    f32x4 v = NT ? __builtin_nontemporal_load(u + i) : u[i];
+    const float x = NT ? __builtin_nontemporal_load(a + i) : a[i], y = NT ? __builtin_nontemporal_load(b2 + i) : b2[i];
+    v.x += x; v.y += y; v.z *= x; v.w *= y;
+    if (NT) __builtin_nontemporal_store(v, o + i); else o[i] = v;
+}
+
 template <class F> static float timeit(F f, int iters = 10)
 {
     hipEvent_t a, b;
@@ -88,7 +119,26 @@ int main()
         ms = timeit([&] { hipLaunchKernelGGL((rows41<false, 16>), dim3(g), dim3(64), 0, 0, u, o, T, ncols); });
         printf("  rows   plain 16 rows in flight, %d waves : %.3f ms  %6.0f GB/s (%.1f %% of 8 TB/s)\n", g, ms, bytes / ms / 1e6, bytes / ms / 8e7);
     }
-    // read-only and write-only ceilings with the same element count
+    {
+        const long long n4 = n / 4;
+        float ms = timeit([&] { hipLaunchKernelGGL((mix41_wide<true>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, 0, u, (f32x4 *)o, n4); });
+        printf("  flat   nt    4 elements per thread, one 16-byte store : %.3f ms  %6.0f GB/s (%.1f %% of 8 TB/s)\n", ms, bytes / ms / 1e6, bytes / ms / 8e7);
+        ms = timeit([&] { hipLaunchKernelGGL((mix41_wide<false>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, 0, u, (f32x4 *)o, n4); });
+        printf("  flat   plain 4 elements per thread, one 16-byte store : %.3f ms  %6.0f GB/s (%.1f %% of 8 TB/s)\n", ms, bytes / ms / 1e6, bytes / ms / 8e7);
+    }
     CHECK(hipFree(u)); CHECK(hipFree(o));
+    {   // the backward scan at the training size: 2000 x 64 320 elements, 24 B read + 16 B written
+        const long long nb = 2000LL * 64320;
+        f32x4 *bu, *bo; float *ba, *bb;
+        CHECK(hipMalloc(&bu, nb * 16)); CHECK(hipMalloc(&bo, nb * 16)); CHECK(hipMalloc(&ba, nb * 4)); CHECK(hipMalloc(&bb, nb * 4));
+        CHECK(hipMemset(bu, 0, nb * 16)); CHECK(hipMemset(ba, 0, nb * 4)); CHECK(hipMemset(bb, 0, nb * 4));
+        const double bbytes = 40.0 * nb;
+        const int g = (int)((nb + 255) / 256);
+        float ms = timeit([&] { hipLaunchKernelGGL((mix2416<true>), dim3(g), dim3(256), 0, 0, bu, ba, bb, bo, nb); });
+        printf("backward mix (24 B read + 16 B written, %lld elements): nt    %.3f ms  %6.0f GB/s (%.1f %% of 8 TB/s)\n", nb, ms, bbytes / ms / 1e6, bbytes / ms / 8e7);
+        ms = timeit([&] { hipLaunchKernelGGL((mix2416<false>), dim3(g), dim3(256), 0, 0, bu, ba, bb, bo, nb); });
+        printf("backward mix (24 B read + 16 B written, %lld elements): plain %.3f ms  %6.0f GB/s (%.1f %% of 8 TB/s)\n", nb, ms, bbytes / ms / 1e6, bbytes / ms / 8e7);
+        CHECK(hipFree(bu)); CHECK(hipFree(bo)); CHECK(hipFree(ba)); CHECK(hipFree(bb));
+    }
     return 0;
 }
