@@ -16,11 +16,6 @@ def medians(path):
     return {k: statistics.median(v) for k, v in agg.items()}
 
 
-def pair(ftag, wtag, base=root):
-    f = medians(os.path.join(base, ftag, ftag.split("/")[-1] + "_counter_collection.csv")) if not ftag.startswith("@") else {}
-    return f
-
-
 fetch = medians(os.path.join(root, "r2f", "r2f_counter_collection.csv"))
 write = medians(os.path.join(root, "r2w", "r2w_counter_collection.csv"))
 fetch.update(medians(os.path.join(root, "scf", "scf_counter_collection.csv")))
