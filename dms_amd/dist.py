@@ -66,10 +66,12 @@ class OverlappedGradReducer(object):
     ``_staged`` below): the copies overlap backward, the host all-reduce runs in ``finish()``.
     """
 
-    def __init__(self, params, bucket_mb=128, average=True, group=None):
+    def __init__(self, params, bucket_mb=128, average=True, group=None, collective_at_world_1=False):
         self.params = [p for p in params if p.requires_grad]
         self.group, self.average = group, average
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        # test hook: issue the collectives even in a one-rank group (exercises the RCCL path on one GPU)
+        self._collective = self.world > 1 or (collective_at_world_1 and dist.is_available() and dist.is_initialized())
         limit = max(int(bucket_mb * (1 << 20) // 4), 1)
         # buckets over the parameters in reverse order
         plan, cur, count = [], [], 0
@@ -102,7 +104,7 @@ class OverlappedGradReducer(object):
         # hung on the MI355X box in the second training step -- both ranks inside wait() of the first
         # bucket, same launch order on both (profiles/r2_train320_2rank_gloo.md) -- and host tensors are
         # what gloo reduces anyway.  RCCL ("nccl") reduces the device buckets in place.
-        self._staged = (self.world > 1 and self.buckets and self.buckets[0].is_cuda
+        self._staged = (self._collective and self.buckets and self.buckets[0].is_cuda
                         and dist.get_backend(group) == "gloo")
         if self._staged:
             self._side = torch.cuda.Stream(device=self.buckets[0].device)
@@ -113,7 +115,7 @@ class OverlappedGradReducer(object):
         if self._work[bi] is not None:
             return
         self.launch_log.append((bi, self._in_backward))
-        if self.world <= 1:
+        if not self._collective:
             self._work[bi] = True
         elif self._staged:
             # gloo with device buckets: start the bucket's copy to pinned host memory on the side
@@ -149,7 +151,7 @@ class OverlappedGradReducer(object):
         self._in_backward = False
         for bi in range(len(self.buckets)):
             self._launch(bi)
-        if self._staged and self.world > 1:
+        if self._staged:
             works = []
             for bi, done in enumerate(self._work):
                 done.synchronize()                                   # the bucket is in host memory

@@ -70,3 +70,50 @@ def test_device_buckets_over_gloo_world2_three_steps_equal_the_single_process_gr
         torch.testing.assert_close(got["grad"], ref, rtol=2e-5, atol=1e-6)
         assert got["calls"] == len(got["in_bwd"]) >= 3
         assert all(inb for _, inb in got["in_bwd"])               # every bucket's copy started from a hook
+
+
+def _rccl_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world)       # "nccl" IS RCCL on ROCm
+    try:
+        dev = torch.device("cuda", 0)
+        model = _toy().to(dev)
+        red = OverlappedGradReducer(list(model.parameters()), bucket_mb=0.1, average=True, collective_at_world_1=True)
+        assert not red._staged and len(red.buckets) >= 3
+        x = (torch.arange(16 * 64, dtype=torch.float32).view(16, 64) % 13 - 6.0) / 10.0
+        steps = []
+        for step in range(3):
+            red.zero_grad()
+            red.launch_log = []
+            model(x.to(dev) * (step + 1)).pow(2).mean().backward()
+            in_bwd = list(red.launch_log)
+            calls = red.finish()
+            torch.cuda.synchronize()
+            steps.append({"grad": torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu(),
+                          "calls": calls, "in_bwd": in_bwd})
+        t = torch.ones(4, device=dev)
+        dist.all_reduce(t)
+        dist.barrier()
+        torch.save({"steps": steps, "sum": t.cpu()}, out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(240)
+def test_device_buckets_through_rccl_in_place_one_rank_group(tmp_path):
+    """The RCCL code path of the reducer (async all-reduce of the device buckets IN PLACE, launched from
+    autograd hooks, waited for in finish()) on the one GPU there is: a one-rank "nccl" group with the
+    reducer told to issue its collectives anyway.  Gradients must equal plain autograd's."""
+    assert torch.cuda.is_available(), "this test needs a real MI355X"
+    out = str(tmp_path / "r.pt")
+    mp.spawn(_rccl_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    got = torch.load(out)
+    assert torch.equal(got["sum"], torch.ones(4))
+    x = (torch.arange(16 * 64, dtype=torch.float32).view(16, 64) % 13 - 6.0) / 10.0
+    for step, g in enumerate(got["steps"]):
+        model = _toy()
+        model(x * (step + 1)).pow(2).mean().backward()
+        ref = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+        torch.testing.assert_close(g["grad"], ref, rtol=2e-5, atol=1e-6)
+        assert g["calls"] == len(g["in_bwd"]) >= 3 and all(inb for _, inb in g["in_bwd"])
