@@ -89,8 +89,8 @@ class LaunchTimer(object):
         if name == "dmn_cat_upsample2x_bwd":
             B, Cx, Cf, H, W = args[3:8]
             return "cat_upsample2x_bwd %dx%d" % (H, W), 4 * B * (Cx + Cf) * H * W * 5
-        if name == "dmn_dynfilter_fwd":
-            B, L, K, C, S = args[3:8]
+        if name in ("dmn_dynfilter_fwd", "dmn_dynfilter_fwd_ws"):
+            B, L, K, C, S = args[3:8] if name == "dmn_dynfilter_fwd" else args[4:9]
             return "dynfilter_fwd", 4 * B * (C * S + L * K * C + L * K * S)
         if name == "dmn_mix_sru_fwd":
             B, L, K, S, d = args[9:14]
@@ -160,8 +160,8 @@ class LaunchTimer(object):
         if name == "dmn_gconv3x3_bn_relu":
             N, C, H, W, groups, st = args[9:15]
             return 2 * N * C * (H // st) * (W // st) * (C // groups) * 9
-        if name == "dmn_dynfilter_fwd":
-            B, L, K, C, S = args[3:8]
+        if name in ("dmn_dynfilter_fwd", "dmn_dynfilter_fwd_ws"):
+            B, L, K, C, S = args[3:8] if name == "dmn_dynfilter_fwd" else args[4:9]
             return 2 * B * L * K * C * S
         if name == "dmn_mix_sru_fwd":
             B, L, K, S, d = args[9:14]

@@ -28,6 +28,8 @@ SIGNATURES = {
     "dmn_sru_scan_workspace_floats": [_i, _i, _i, _i],
     "dmn_cat_coords": [_p, _p, _i, _i, _i, _i, _p],
     "dmn_dynfilter_fwd": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "dmn_dynfilter_fwd_ws": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "dmn_dynfilter_workspace_floats": [_i, _i, _i, _i, _i],
     "dmn_dynfilter_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "dmn_mix_bcast_add": [_p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p],
     "dmn_mix_sru_fwd": [_p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
@@ -93,3 +95,8 @@ def call(name, *args):
         raise RuntimeError("%s failed (status %d): %s"
                            % (name, rc, msg.decode("utf-8", "replace") if msg else "?"))
     return rc
+
+
+def query(name, *args):
+    """Invoke an entry point that returns a VALUE (a size), not a status."""
+    return int(getattr(load(), name)(*args))

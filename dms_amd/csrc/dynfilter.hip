@@ -23,15 +23,26 @@ __device__ __forceinline__ long long lbk_row(int r, int b, int B, int K, int ld)
 }
 
 // ---- forward, vector path: C % 4 == 0, S % 4 == 0, 16-byte aligned bases -------------
+// The contraction over C runs in DF_NCH chunks of `spc` K-steps: every chunk is accumulated from zero and
+// the chunk sums are added in chunk order.  One workgroup does all chunks of its tile (SPLIT = false), or --
+// few samples: 16 tiles per sample cannot fill 256 CUs, round 2 -- one workgroup per (tile, chunk) writes its
+// chunk sum to a workspace (ws[chunk][b][r][s]) and dynfilter_reduce adds them in the same order.  Both
+// forms give the SAME bits, so a sample's result does not depend on the batch it arrives in.
+constexpr int DF_NCH = 16;
+
+template <bool SPLIT>
 __global__ void __launch_bounds__(256)
 dynfilter_fwd_vec(const float *__restrict__ V, const float *__restrict__ F, float *__restrict__ P,
-                  int B, int R, int K, int C, int S)
+                  int B, int R, int K, int C, int S, int spc, int nch)
 {
     __shared__ float As[BK][BM + PAD];   // As[kk][row]  (transposed on store)
     __shared__ float Bs[BK][BN + PAD];   // Bs[kk][col]
-    const int b = blockIdx.z, r0 = blockIdx.y * BM, s0 = blockIdx.x * BN;
+    const int b = SPLIT ? (int)blockIdx.z / nch : (int)blockIdx.z, ch = SPLIT ? (int)blockIdx.z % nch : 0;
+    const int r0 = blockIdx.y * BM, s0 = blockIdx.x * BN;
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const float *Vb = V + (long long)b * C * S;
+    const int steps = (C + BK - 1) / BK;
+    const int st_lo = SPLIT ? ch * spc : 0, st_hi = SPLIT ? min(steps, (ch + 1) * spc) : steps;
 
     // this lane's slice of the two tiles
     const int ar = tid >> 2, ac = (tid & 3) * 4;     // A: row ar, k-offset ac..ac+3
@@ -41,21 +52,22 @@ dynfilter_fwd_vec(const float *__restrict__ V, const float *__restrict__ F, floa
     const bool b_ok = (s0 + bc) < S;                 // S % 4 == 0 -> whole float4 in or out
 
     // column pairs ride v_pk_fma_f32 (the filter value is broadcast by op_sel): twice the FMA rate
-    f32x2_t acc2[4][2];
+    f32x2_t acc2[4][2], tot2[4][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc2[i][0] = acc2[i][1] = (f32x2_t){0.0f, 0.0f};
+    for (int i = 0; i < 4; ++i) acc2[i][0] = acc2[i][1] = tot2[i][0] = tot2[i][1] = (f32x2_t){0.0f, 0.0f};
     float4 av = make_float4(0, 0, 0, 0), bv = make_float4(0, 0, 0, 0);
     auto fetch = [&](int c0) {
         av = (a_ok && c0 + ac < C) ? *reinterpret_cast<const float4 *>(Ap + c0 + ac) : make_float4(0, 0, 0, 0);
         bv = (b_ok && c0 + bk < C) ? *reinterpret_cast<const float4 *>(Vb + (long long)(c0 + bk) * S + s0 + bc)
                                    : make_float4(0, 0, 0, 0);
     };
-    fetch(0);
-    for (int c0 = 0; c0 < C; c0 += BK) {
+    if (st_lo < st_hi) fetch(st_lo * BK);
+    int left = spc;                                  // K-steps left in the current chunk
+    for (int st = st_lo; st < st_hi; ++st) {
         As[ac + 0][ar] = av.x; As[ac + 1][ar] = av.y; As[ac + 2][ar] = av.z; As[ac + 3][ar] = av.w;
         *reinterpret_cast<float4 *>(&Bs[bk][bc]) = bv;
         __syncthreads();
-        if (c0 + BK < C) fetch(c0 + BK);
+        if (st + 1 < st_hi) fetch((st + 1) * BK);
 #pragma unroll
         for (int kk = 0; kk < BK; ++kk) {
             const float4 a = *reinterpret_cast<const float4 *>(&As[kk][ty * 4]);
@@ -70,17 +82,48 @@ dynfilter_fwd_vec(const float *__restrict__ V, const float *__restrict__ F, floa
             }
         }
         __syncthreads();
+        if (!SPLIT && (--left == 0 || st + 1 == st_hi)) {       // chunk boundary: fold the chunk sum in
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                tot2[i][0] += acc2[i][0]; tot2[i][1] += acc2[i][1];
+                acc2[i][0] = acc2[i][1] = (f32x2_t){0.0f, 0.0f};
+            }
+            left = spc;
+        }
     }
     const int sc = s0 + tx * 4;
     if (sc < S) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = r0 + ty * 4 + i;
-            if (r < R)
-                *reinterpret_cast<float4 *>(P + lbk_row(r, b, B, K, S) + sc) =
+            if (r >= R) continue;
+            if (SPLIT)
+                *reinterpret_cast<float4 *>(P + (((long long)ch * B + b) * R + r) * S + sc) =
                     make_float4(acc2[i][0].x, acc2[i][0].y, acc2[i][1].x, acc2[i][1].y);
+            else
+                *reinterpret_cast<float4 *>(P + lbk_row(r, b, B, K, S) + sc) =
+                    make_float4(tot2[i][0].x, tot2[i][0].y, tot2[i][1].x, tot2[i][1].y);
         }
     }
+}
+
+// P[t,b,k,s] = sum over chunks (in chunk order, starting from +0) of ws[chunk][b][r][s]
+__global__ void __launch_bounds__(256)
+dynfilter_reduce(const float *__restrict__ ws, float *__restrict__ P, int B, int R, int K, int S, int nch)
+{
+    const long long i4 = (long long)blockIdx.x * 256 + threadIdx.x;      // float4 index into (B, R, S)
+    const long long per = (long long)B * R * S;
+    if (i4 * 4 >= per) return;
+    float4 tot = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int ch = 0; ch < nch; ++ch) {
+        const float4 v = *reinterpret_cast<const float4 *>(ws + ch * per + i4 * 4);
+        tot.x += v.x; tot.y += v.y; tot.z += v.z; tot.w += v.w;
+    }
+    const long long e = i4 * 4;
+    const int sc = (int)(e % S);
+    const long long br = e / S;
+    const int r = (int)(br % R), b = (int)(br / R);
+    *reinterpret_cast<float4 *>(P + lbk_row(r, b, B, K, S) + sc) = tot;
 }
 
 // ---- generic tiled GEMM with element-wise guarded loads -------------------------------
@@ -175,19 +218,65 @@ static int check_sizes(const char *fn, int B, int L, int K, int C, int S)
 
 using namespace dmn;
 
-extern "C" int dmn_dynfilter_fwd(const float *V, const float *F, float *P, int B, int L, int K,
-                                 int C, int S, void *stream)
+// K-steps per chunk / number of non-empty chunks of the chunked contraction (see dynfilter_fwd_vec)
+static void df_chunks(int C, int *spc, int *nch)
 {
-    if (!V || !F || !P) return fail(-1, "dmn_dynfilter_fwd: NULL pointer");
-    if (int rc = check_sizes("dmn_dynfilter_fwd", B, L, K, C, S)) return rc;
+    const int steps = (C + BK - 1) / BK;
+    *spc = (steps + DF_NCH - 1) / DF_NCH;
+    *nch = (steps + *spc - 1) / *spc;
+}
+
+extern "C" int dmn_dynfilter_workspace_floats(int B, int L, int K, int C, int S)
+{
+    int spc, nch;
+    if (B <= 0 || L <= 0 || K <= 0 || C <= 0 || S <= 0) return 0;
+    df_chunks(C, &spc, &nch);
+    const long long n = (long long)nch * B * L * K * S;
+    return n > 0x7fffffffLL ? 0 : (int)n;           // 0: too large, call without a workspace
+}
+
+static int dynfilter_fwd_impl(const char *fn, const float *V, const float *F, float *P, float *workspace,
+                              int B, int L, int K, int C, int S, void *stream)
+{
+    if (!V || !F || !P) return fail(-1, "%s: NULL pointer", fn);
+    if (int rc = check_sizes(fn, B, L, K, C, S)) return rc;
     const int R = L * K;
     dim3 grid((S + BN - 1) / BN, (R + BM - 1) / BM, B);
     hipStream_t s = (hipStream_t)stream;
     const bool vec = (C % 4 == 0) && (S % 4 == 0) &&
                      !(((uintptr_t)V | (uintptr_t)F | (uintptr_t)P) & 15);
-    if (vec) hipLaunchKernelGGL(dynfilter_fwd_vec, grid, dim3(256), 0, s, V, F, P, B, R, K, C, S);
-    else hipLaunchKernelGGL(dynfilter_generic<0>, grid, dim3(256), 0, s, V, F, (const float *)nullptr, P, B, R, K, C, S);
-    return launch_status("dmn_dynfilter_fwd");
+    if (!vec) {
+        hipLaunchKernelGGL(dynfilter_generic<0>, grid, dim3(256), 0, s, V, F, (const float *)nullptr, P, B, R, K, C, S);
+        return launch_status(fn);
+    }
+    int spc, nch;
+    df_chunks(C, &spc, &nch);
+    // one workgroup per (tile, chunk) while whole tiles would leave CUs idle (measured: tools/dynfilter_bench.py)
+    const char *se = getenv("DMN_DYNFILTER_SPLIT");
+    const long long tiles = (long long)grid.x * grid.y * B;
+    bool split = workspace && nch > 1 && !((uintptr_t)workspace & 15) && (long long)B * nch <= 65535 &&
+                 (se ? atoi(se) != 0 : tiles < 4 * NUM_CU);
+    if (split) {
+        dim3 sgrid(grid.x, grid.y, B * nch);
+        hipLaunchKernelGGL(dynfilter_fwd_vec<true>, sgrid, dim3(256), 0, s, V, F, workspace, B, R, K, C, S, spc, nch);
+        const long long n4 = (long long)B * R * S / 4;
+        hipLaunchKernelGGL(dynfilter_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, workspace, P, B, R, K, S, nch);
+    } else {
+        hipLaunchKernelGGL(dynfilter_fwd_vec<false>, grid, dim3(256), 0, s, V, F, P, B, R, K, C, S, spc, nch);
+    }
+    return launch_status(fn);
+}
+
+extern "C" int dmn_dynfilter_fwd(const float *V, const float *F, float *P, int B, int L, int K,
+                                 int C, int S, void *stream)
+{
+    return dynfilter_fwd_impl("dmn_dynfilter_fwd", V, F, P, nullptr, B, L, K, C, S, stream);
+}
+
+extern "C" int dmn_dynfilter_fwd_ws(const float *V, const float *F, float *P, float *workspace, int B, int L,
+                                    int K, int C, int S, void *stream)
+{
+    return dynfilter_fwd_impl("dmn_dynfilter_fwd_ws", V, F, P, workspace, B, L, K, C, S, stream);
 }
 
 extern "C" int dmn_dynfilter_bwd(const float *V, const float *F, const float *gP, float *gV,

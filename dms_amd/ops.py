@@ -302,7 +302,14 @@ class _DynFilter(torch.autograd.Function):
         _chk("dynfilter", F)
         with torch.cuda.device(V.device):
             P = torch.empty((L, B, K, S), device=V.device, dtype=torch.float32)
-            _lib.call("dmn_dynfilter_fwd", _ptr(V), _ptr(F), _ptr(P), B, L, K, C, S, _stream())
+            # few samples: a workspace lets the library spread the contraction over more workgroups
+            # (same bits either way); 16 tiles per sample at 512 px, so below ~64 samples
+            nws = _lib.query("dmn_dynfilter_workspace_floats", B, L, K, C, S) if B * ((L * K + 63) // 64) * ((S + 63) // 64) < 1024 else 0
+            if nws > 0:
+                ws = torch.empty((nws,), device=V.device, dtype=torch.float32)
+                _lib.call("dmn_dynfilter_fwd_ws", _ptr(V), _ptr(F), _ptr(P), _ptr(ws), B, L, K, C, S, _stream())
+            else:
+                _lib.call("dmn_dynfilter_fwd", _ptr(V), _ptr(F), _ptr(P), B, L, K, C, S, _stream())
         ctx.save_for_backward(V, F)
         return P
 

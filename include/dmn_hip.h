@@ -136,6 +136,16 @@ int dmn_cat_coords(const float *vis, float *V, int B, int C, int H, int W, void 
 int dmn_dynfilter_fwd(const float *V, const float *F, float *P,
                       int B, int L, int K, int C, int S, void *stream);
 
+/*
+ * The same with a caller-provided workspace of dmn_dynfilter_workspace_floats(B, L, K, C, S) floats
+ * (16-byte aligned; NULL = dmn_dynfilter_fwd).  With few samples the contraction over C is spread over
+ * one workgroup per (tile, chunk) and a reduction pass; the chunk order of the summation is the same
+ * either way, so P is bit-identical to dmn_dynfilter_fwd's (dmn.py:178-184, batch-1 serving).
+ */
+int dmn_dynfilter_fwd_ws(const float *V, const float *F, float *P, float *workspace,
+                         int B, int L, int K, int C, int S, void *stream);
+int dmn_dynfilter_workspace_floats(int B, int L, int K, int C, int S);   /* 0 = none / too large */
+
 /* gradients of the above: gF (L,B,K,C) = gP . V^T ; gV (B,C,S) = sum_{t,k} F * gP */
 int dmn_dynfilter_bwd(const float *V, const float *F, const float *gP,
                       float *gV, float *gF,

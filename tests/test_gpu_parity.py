@@ -252,6 +252,29 @@ def test_dynfilter_matches_per_word_conv2d(B, L, K, C, S):
     assert rel_err(P, ref) < 1e-5       # 2696-long fp32 sums vs an fp64 reference
 
 
+@pytest.mark.parametrize("B,L,K,C,S", [(1, 20, 10, 2696, 256), (2, 20, 10, 2696, 100), (3, 5, 3, 40, 12),
+                                       (1, 2, 2, 16, 4), (2, 7, 9, 1000, 64), (5, 20, 10, 264, 256)])
+def test_dynfilter_split_contraction_is_bit_identical_to_the_whole_tile_kernel(B, L, K, C, S, monkeypatch):
+    """One workgroup per (tile, chunk of C) + reduction (few samples) must give the SAME bits as one
+    workgroup per tile (the chunk order of the summation is fixed), so that a sample's filter responses
+    do not depend on the batch it arrives in; both against the float64 einsum."""
+    V = det_uniform((B, C, S), 96, 1.0).to(DEV)
+    Fi = torch.sigmoid(det_uniform((L, B, K, C), 97, 2.0)).to(DEV)
+    ref = torch.einsum("tbkc,bcs->tbks", Fi.double().cpu(), V.double().cpu())
+    monkeypatch.setenv("DMN_DYNFILTER_SPLIT", "1")
+    split = ops.dynfilter(V, Fi)
+    monkeypatch.setenv("DMN_DYNFILTER_SPLIT", "0")
+    whole = ops.dynfilter(V, Fi)
+    monkeypatch.delenv("DMN_DYNFILTER_SPLIT")
+    auto = ops.dynfilter(V, Fi)
+    assert torch.equal(split, whole) and torch.equal(auto, whole)
+    assert rel_err(whole.cpu(), ref) < 1e-5
+    # a sample alone == the same sample inside the batch, bit for bit
+    if B > 1:
+        alone = ops.dynfilter(V[1:2].contiguous(), Fi[:, 1:2].contiguous())
+        assert torch.equal(alone[:, 0], whole[:, 1])
+
+
 def test_dynfilter_bwd_matches_autograd():
     B, L, K, C, S = 2, 5, 3, 41, 18
     V = det_uniform((B, C, S), 93, 1.0)
