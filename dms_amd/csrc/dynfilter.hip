@@ -206,6 +206,82 @@ dynfilter_generic(const float *__restrict__ V, const float *__restrict__ X /*F o
     }
 }
 
+// ---- backward, vector paths (round 2): C % 4 == 0, S % 4 == 0, 16-byte aligned bases -------------------
+// The generic kernel above fetches every tile element with its own guarded 4-byte load (and a division
+// for the (t, k) row address); these read 16 bytes per lane along the contiguous axis and ride
+// v_pk_fma_f32 like the forward.  MODE 1: gF[r,c] = sum_s gP[r,s] V[c,s] (both operands s-contiguous:
+// transposed on the way into LDS).  MODE 2: gV[c,s] = sum_r F[r,c] gP[r,s] (both operands contiguous
+// along the tile axes: straight 16-byte copies into LDS).
+template <int MODE>
+__global__ void __launch_bounds__(256)
+dynfilter_bwd_vec(const float *__restrict__ V, const float *__restrict__ F, const float *__restrict__ gP,
+                  float *__restrict__ O, int B, int R, int K, int C, int S)
+{
+    __shared__ float As[BK][BM + PAD];
+    __shared__ float Bs[BK][BN + PAD];
+    const int b = blockIdx.z, m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const float *Vb = V + (long long)b * C * S;
+    const int Md = (MODE == 2) ? C : R, Nd = (MODE == 1) ? C : S, Kd = (MODE == 1) ? S : R;
+
+    f32x2_t acc2[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc2[i][0] = acc2[i][1] = (f32x2_t){0.0f, 0.0f};
+    float4 av = make_float4(0, 0, 0, 0), bv = make_float4(0, 0, 0, 0);
+    // MODE 1: lane -> (row tid >> 2, k-offset (tid & 3) * 4) of both operands (k-contiguous)
+    // MODE 2: lane -> (k-row tid >> 4, tile offset (tid & 15) * 4) of both operands (tile-contiguous)
+    const int rr = (MODE == 1) ? tid >> 2 : tid >> 4, off = (MODE == 1) ? (tid & 3) * 4 : (tid & 15) * 4;
+    const bool a_row_ok = (MODE == 1) ? (m0 + rr) < R : true;
+    const float *Arow = (MODE == 1) ? gP + (a_row_ok ? lbk_row(m0 + rr, b, B, K, S) : 0) : nullptr;
+    auto fetch = [&](int k0) {
+        const float4 z = make_float4(0, 0, 0, 0);
+        if (MODE == 1) {
+            av = (a_row_ok && k0 + off < S) ? *reinterpret_cast<const float4 *>(Arow + k0 + off) : z;
+            bv = ((n0 + rr) < C && k0 + off < S) ? *reinterpret_cast<const float4 *>(Vb + (long long)(n0 + rr) * S + k0 + off) : z;
+        } else {
+            const int r = k0 + rr;
+            av = (r < R && m0 + off < C) ? *reinterpret_cast<const float4 *>(F + lbk_row(r, b, B, K, C) + m0 + off) : z;
+            bv = (r < R && n0 + off < S) ? *reinterpret_cast<const float4 *>(gP + lbk_row(r, b, B, K, S) + n0 + off) : z;
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < Kd; k0 += BK) {
+        if (MODE == 1) {
+            As[off + 0][rr] = av.x; As[off + 1][rr] = av.y; As[off + 2][rr] = av.z; As[off + 3][rr] = av.w;
+            Bs[off + 0][rr] = bv.x; Bs[off + 1][rr] = bv.y; Bs[off + 2][rr] = bv.z; Bs[off + 3][rr] = bv.w;
+        } else {
+            *reinterpret_cast<float4 *>(&As[rr][off]) = av;
+            *reinterpret_cast<float4 *>(&Bs[rr][off]) = bv;
+        }
+        __syncthreads();
+        if (k0 + BK < Kd) fetch(k0 + BK);
+#pragma unroll
+        for (int kk = 0; kk < BK; ++kk) {
+            const float4 a = *reinterpret_cast<const float4 *>(&As[kk][ty * 4]);
+            const float4 w = *reinterpret_cast<const float4 *>(&Bs[kk][tx * 4]);
+            const float aa[4] = {a.x, a.y, a.z, a.w};
+            const f32x2_t w01 = {w.x, w.y}, w23 = {w.z, w.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x2_t ai = {aa[i], aa[i]};
+                acc2[i][0] = __builtin_elementwise_fma(ai, w01, acc2[i][0]);
+                acc2[i][1] = __builtin_elementwise_fma(ai, w23, acc2[i][1]);
+            }
+        }
+        __syncthreads();
+    }
+    const int n = n0 + tx * 4;
+    if (n < Nd) {                                    // Nd % 4 == 0: whole float4 in or out
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + ty * 4 + i;
+            if (m >= Md) continue;
+            float *dst = (MODE == 1) ? O + lbk_row(m, b, B, K, C) + n : O + ((long long)b * C + m) * S + n;
+            *reinterpret_cast<float4 *>(dst) = make_float4(acc2[i][0].x, acc2[i][0].y, acc2[i][1].x, acc2[i][1].y);
+        }
+    }
+}
+
 static int check_sizes(const char *fn, int B, int L, int K, int C, int S)
 {
     if (B <= 0 || L <= 0 || K <= 0 || C <= 0 || S <= 0)
@@ -286,13 +362,18 @@ extern "C" int dmn_dynfilter_bwd(const float *V, const float *F, const float *gP
     if (int rc = check_sizes("dmn_dynfilter_bwd", B, L, K, C, S)) return rc;
     const int R = L * K;
     hipStream_t s = (hipStream_t)stream;
+    const char *ve = getenv("DMN_DYNFILTER_BWD_VEC");
+    const bool vec = (C % 4 == 0) && (S % 4 == 0) && !(ve && atoi(ve) == 0) &&
+                     !(((uintptr_t)V | (uintptr_t)F | (uintptr_t)gP | (uintptr_t)gV | (uintptr_t)gF) & 15);
     if (gF) {
         dim3 grid((C + BN - 1) / BN, (R + BM - 1) / BM, B);
-        hipLaunchKernelGGL(dynfilter_generic<1>, grid, dim3(256), 0, s, V, gP, (const float *)nullptr, gF, B, R, K, C, S);
+        if (vec) hipLaunchKernelGGL(dynfilter_bwd_vec<1>, grid, dim3(256), 0, s, V, F, gP, gF, B, R, K, C, S);
+        else hipLaunchKernelGGL(dynfilter_generic<1>, grid, dim3(256), 0, s, V, gP, (const float *)nullptr, gF, B, R, K, C, S);
     }
     if (gV) {
         dim3 grid((S + BN - 1) / BN, (C + BM - 1) / BM, B);
-        hipLaunchKernelGGL(dynfilter_generic<2>, grid, dim3(256), 0, s, V, F, gP, gV, B, R, K, C, S);
+        if (vec) hipLaunchKernelGGL(dynfilter_bwd_vec<2>, grid, dim3(256), 0, s, V, F, gP, gV, B, R, K, C, S);
+        else hipLaunchKernelGGL(dynfilter_generic<2>, grid, dim3(256), 0, s, V, F, gP, gV, B, R, K, C, S);
     }
     return launch_status("dmn_dynfilter_bwd");
 }

@@ -275,16 +275,24 @@ def test_dynfilter_split_contraction_is_bit_identical_to_the_whole_tile_kernel(B
         assert torch.equal(alone[:, 0], whole[:, 1])
 
 
-def test_dynfilter_bwd_matches_autograd():
-    B, L, K, C, S = 2, 5, 3, 41, 18
+@pytest.mark.parametrize("B,L,K,C,S", [(2, 5, 3, 41, 18), (2, 20, 10, 2696, 100), (1, 20, 10, 264, 256),
+                                       (3, 7, 9, 40, 12), (1, 2, 2, 16, 4), (2, 3, 5, 68, 64)])
+def test_dynfilter_bwd_matches_autograd(B, L, K, C, S, monkeypatch):
+    """gV, gF vs float64 autograd of the einsum; the 16-byte-load kernels (C, S multiples of 4) and the
+    element-wise guarded ones agree."""
     V = det_uniform((B, C, S), 93, 1.0)
     Fi = det_uniform((L, B, K, C), 94, 1.0)
     gP = det_uniform((L, B, K, S), 95, 1.0)
-    Vg, Fg = V.to(DEV).requires_grad_(True), Fi.to(DEV).requires_grad_(True)
-    (ops.dynfilter(Vg, Fg) * gP.to(DEV)).sum().backward()
     Vr, Fr = V.clone().double().requires_grad_(True), Fi.clone().double().requires_grad_(True)
     (torch.einsum("tbkc,bcs->tbks", Fr, Vr) * gP.double()).sum().backward()
-    assert rel_err(Vg.grad.cpu(), Vr.grad) < 1e-5 and rel_err(Fg.grad.cpu(), Fr.grad) < 1e-5
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("DMN_DYNFILTER_BWD_VEC", mode)
+        Vg, Fg = V.to(DEV).requires_grad_(True), Fi.to(DEV).requires_grad_(True)
+        (ops.dynfilter(Vg, Fg) * gP.to(DEV)).sum().backward()
+        assert rel_err(Vg.grad.cpu(), Vr.grad) < 1e-5 and rel_err(Fg.grad.cpu(), Fr.grad) < 1e-5, mode
+        got[mode] = (Vg.grad.cpu(), Fg.grad.cpu())
+    assert rel_err(got["1"][0], got["0"][0]) < 2e-6 and rel_err(got["1"][1], got["0"][1]) < 2e-6
 
 
 def _mix_ref(A, Bt, P, Wp):

@@ -25,3 +25,24 @@ for B in (1, 2, 4, 8, 16, 32, 64):
     fl = 2.0 * B * L * K * C * S
     print("B=%2d: whole tiles %.4f ms (%.1f TFLOP/s)   split %.4f ms (%.1f TFLOP/s)" % (
         B, res[0], fl / res[0] / 1e9, res[1], fl / res[1] / 1e9), flush=True)
+
+# backward at the training shape (configs[3]: 320 px low-res, S = 100, B = 64)
+from dms_amd import _lib
+B, S = 64, 100
+g = torch.Generator(device=dev).manual_seed(7)
+V = torch.randn((B, C, S), device=dev, generator=g); F = torch.rand((L, B, K, C), device=dev, generator=g)
+gP = torch.randn((L, B, K, S), device=dev, generator=g)
+gV = torch.empty_like(V); gF = torch.empty_like(F)
+st = torch.cuda.current_stream().cuda_stream
+for mode in ("0", "1"):
+    os.environ["DMN_DYNFILTER_BWD_VEC"] = mode
+    fn = lambda: _lib.call("dmn_dynfilter_bwd", V.data_ptr(), F.data_ptr(), gP.data_ptr(), gV.data_ptr(), gF.data_ptr(), B, L, K, C, S, st)
+    for _ in range(3):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(20):
+        fn()
+    b.record(); torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / 20
+    print("dynfilter_bwd B=%d S=%d vec=%s: %.4f ms  %.1f TFLOP/s" % (B, S, mode, ms, 4.0 * B * L * K * C * S / ms / 1e9), flush=True)
