@@ -197,9 +197,14 @@ constexpr int MIX_BWD2_K = 10, MIX_BWD2_NW = 6;
 template <int NW, int PT>
 __global__ void __launch_bounds__(512)
 mix_bwd_pix2_kernel(const float *__restrict__ gQ, const float *__restrict__ Wp, int ldw,
-                    float *__restrict__ gA, float *__restrict__ gP, int B, int L, int K, int S, int M)
+                    float *__restrict__ gA, float *__restrict__ gP, int B, int L, int K, int S, int Mfull,
+                    int m_off, int accumulate)
 {
+    // columns m_off .. m_off + M - 1 of the Mfull-wide rows (M <= 1024 per launch; wider rows are swept by
+    // consecutive launches on the same stream, the later ones ADDING their share into gP: fixed order)
     constexpr int KR = MIX_BWD2_K;
+    const int M = min(1024, Mfull - m_off);
+    gQ += m_off; gA += m_off; Wp += (long long)m_off * ldw;
     extern __shared__ float lds2[];                 // Wl[KR][1024] while the weights are fetched, then ga_lds[4][M] + red[4][64]
     const int b = blockIdx.y, s0 = blockIdx.x * PT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -227,7 +232,7 @@ mix_bwd_pix2_kernel(const float *__restrict__ gQ, const float *__restrict__ Wp, 
     auto load_word = [&](int s, int tt) {
         const int t = wq + 4 * tt;
         const bool ok = t < L && s < S;
-        const float *gr = gQ + (((long long)(ok ? s : 0) * L + (ok ? t : 0)) * B + b) * M;
+        const float *gr = gQ + (((long long)(ok ? s : 0) * L + (ok ? t : 0)) * B + b) * Mfull;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int m = mbase + 256 * i;
@@ -286,12 +291,16 @@ mix_bwd_pix2_kernel(const float *__restrict__ gQ, const float *__restrict__ Wp, 
         if (s < S) {                                // uniform
             if (half == 0) {
                 const int tt = lane / KR, k = lane - tt * KR, t = wq + 4 * tt;
-                if (tt < NW && t < L && k < K) gP[lbk_off(t, b, k, B, K, S) + s] = v[0] + red[wq * 64 + lane];
+                if (tt < NW && t < L && k < K) {
+                    float *dst = gP + lbk_off(t, b, k, B, K, S) + s;
+                    const float tot = v[0] + red[wq * 64 + lane];
+                    *dst = accumulate ? *dst + tot : tot;
+                }
             }
             for (int m = threadIdx.x * 4; m < M; m += 2048) {
                 const float4 a0 = *reinterpret_cast<const float4 *>(ga_lds + m), a1 = *reinterpret_cast<const float4 *>(ga_lds + 1024 + m);
                 const float4 a2 = *reinterpret_cast<const float4 *>(ga_lds + 2048 + m), a3 = *reinterpret_cast<const float4 *>(ga_lds + 3072 + m);
-                *reinterpret_cast<float4 *>(gA + ((long long)b * S + s) * M + m) =
+                *reinterpret_cast<float4 *>(gA + ((long long)b * S + s) * Mfull + m) =
                     make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y),
                                 (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w));
             }
@@ -373,7 +382,7 @@ mix_bwd_word2_kernel(const float *__restrict__ gQ, const float *__restrict__ P,
     }
     __syncthreads();
     const long long row_stride = (long long)L * B * M;     // between consecutive pixels
-    const int m = threadIdx.x * 4;
+    const int m = ((int)blockIdx.z * 256 + threadIdx.x) * 4;   // blockIdx.z: blocks of 1024 columns
     if (m >= M) return;
     float gb[4] = {0.0f, 0.0f, 0.0f, 0.0f}, gw[4][KR];
 #pragma unroll
@@ -468,27 +477,31 @@ extern "C" int dmn_mix_bcast_add_bwd(const float *gQ, const float *P, const floa
         return fail(-1, "dmn_mix_bcast_add_bwd: NULL pointer");
     if (int rc = check_mix("dmn_mix_bcast_add_bwd", B, L, K, S, M, ldw)) return rc;
     if (K > MIX_KMAX) return fail(-5, "dmn_mix_bcast_add_bwd: K=%d > %d not supported", K, MIX_KMAX);
-    if (M > 1024) return fail(-5, "dmn_mix_bcast_add_bwd: M=%d > 1024 not supported", M);
+    const int nw = (L + 3) / 4;
+    const bool gen2 = K <= MIX_BWD2_K && nw <= MIX_BWD2_NW && M % 4 == 0 && !(((uintptr_t)gA | (uintptr_t)gBt) & 15);
+    if (M > 1024 && !gen2)
+        return fail(-5, "dmn_mix_bcast_add_bwd: M=%d > 1024 needs K <= %d and L <= %d", M, MIX_BWD2_K, 4 * MIX_BWD2_NW);
     const size_t lds = (size_t)K * S * sizeof(float);
     if (lds > 64 * 1024) return fail(-5, "dmn_mix_bcast_add_bwd: K*S=%d too large for the LDS stage", K * S);
     hipStream_t s = (hipStream_t)stream;
     if (M % 4 != 0 || ((uintptr_t)gQ & 15)) return fail(-5, "dmn_mix_bcast_add_bwd: M %% 4 == 0 and 16-byte aligned gQ required");
-    const int nw = (L + 3) / 4;
     const char *pe = getenv("DMN_MIX_BWD_PIX2");
-    if (K <= MIX_BWD2_K && nw <= MIX_BWD2_NW && !(((uintptr_t)gA) & 15) && !(pe && atoi(pe) == 0)) {
+    if (gen2 && (M > 1024 || !(pe && atoi(pe) == 0))) {
         // pixels per workgroup: 5 when that divides S (S = 100 in training: 20 x B workgroups), else 4
         const size_t lds2 = (size_t)MIX_BWD2_K * 1024 * sizeof(float);
-#define DMN_PIX2(NWV, PTV) hipLaunchKernelGGL((mix_bwd_pix2_kernel<NWV, PTV>), dim3((S + PTV - 1) / PTV, B), dim3(512), lds2, s, gQ, Wp, ldw, gA, gP, B, L, K, S, M)
-        if (S % 5 == 0) { if (nw <= 5) DMN_PIX2(5, 5); else DMN_PIX2(6, 5); }
-        else            { if (nw <= 5) DMN_PIX2(5, 4); else DMN_PIX2(6, 4); }
+#define DMN_PIX2(NWV, PTV) hipLaunchKernelGGL((mix_bwd_pix2_kernel<NWV, PTV>), dim3((S + PTV - 1) / PTV, B), dim3(512), lds2, s, gQ, Wp, ldw, gA, gP, B, L, K, S, M, m_off, m_off > 0)
+        for (int m_off = 0; m_off < M; m_off += 1024) {
+            if (S % 5 == 0) { if (nw <= 5) DMN_PIX2(5, 5); else DMN_PIX2(6, 5); }
+            else            { if (nw <= 5) DMN_PIX2(5, 4); else DMN_PIX2(6, 4); }
+        }
 #undef DMN_PIX2
     } else {
         const size_t lds_pix = (size_t)(K + 4) * M * sizeof(float);
         hipLaunchKernelGGL(mix_bwd_pix_kernel, dim3((S + MIX_BWD_PT - 1) / MIX_BWD_PT, B), dim3(256), lds_pix, s, gQ, Wp, ldw, gA, gP, B, L, K, S, M);
     }
     const char *we = getenv("DMN_MIX_BWD_WORD2");
-    if (K <= MIX_BWD2_K && M <= 1024 && !((uintptr_t)gBt & 15) && !(we && atoi(we) == 0))
-        hipLaunchKernelGGL(mix_bwd_word2_kernel<5>, dim3(L, B), dim3(256), (size_t)12 * S * sizeof(float), s, gQ, P, gBt, gWp_part, B, L, K, S, M);
+    if (K <= MIX_BWD2_K && M % 4 == 0 && !((uintptr_t)gBt & 15) && (M > 1024 || !(we && atoi(we) == 0)))
+        hipLaunchKernelGGL(mix_bwd_word2_kernel<5>, dim3(L, B, (M + 1023) / 1024), dim3(256), (size_t)12 * S * sizeof(float), s, gQ, P, gBt, gWp_part, B, L, K, S, M);
     else if ((M % 4 == 0) && !((uintptr_t)gQ & 15))
         hipLaunchKernelGGL(mix_bwd_word_kernel<4>, dim3(L, B), dim3(256), lds, s, gQ, P, gBt, gWp_part, B, L, K, S, M);
     else

@@ -93,6 +93,10 @@ class BaseDMN(nn.Module):
         # with the fold: mix fused into the layer-0 scan (ops.mix_sru_fwd) when the batch is large
         # enough for it to win (MIX_SCAN_MIN_COLS columns); False = mix kernel + scan kernel
         self.fuse_mix_scan = True
+        # the fold under autograd too (round 2): W_fold is then built differentiably every step and
+        # the gradients of comb_conv and of layer 0's weight arrive through it; layer 0's three
+        # (S*L*B) x M x 4Hm GEMMs (forward, dgrad, wgrad) shrink to (S*B) x C x 4Hm ones
+        self.fold_in_training = True
         self._fold_cache = None
         self.base = create_backbone(backend, pretrained=pretrained, extra=extra)
 
@@ -142,14 +146,18 @@ class BaseDMN(nn.Module):
         filt = filt.view(L, B, K, C8)                              # dmn.py:176-177
         P = ops.dynfilter(V, filt)                                 # (L,B,K,S) dmn.py:178-184
 
-        fold = (self.fold_comb_into_msru and not self.lstm and not torch.is_grad_enabled()
-                and self.mrnn.rnn_lst[0].k == 4)
+        grad = torch.is_grad_enabled()
+        fold = (self.fold_comb_into_msru and not self.lstm and self.mrnn.rnn_lst[0].k == 4
+                and (not grad or (self.fold_in_training and K <= 10 and L <= 24)))
         if fold:
             Wv_f, Wl_f, Wp_f, b_f = self._folded_weights()
-            A = ops.tuned_matmul(V.transpose(1, 2), Wv_f)           # (B, S, 4*Hm)
+            if grad:                                                # autograd-visible library GEMMs
+                A = torch.matmul(V.transpose(1, 2), Wv_f)
+            else:
+                A = ops.tuned_matmul(V.transpose(1, 2), Wv_f)       # (B, S, 4*Hm)
             Bt = torch.addmm(b_f, lang_cat, Wl_f).view(L, B, -1)    # (L, B, 4*Hm)
             cell0 = self.mrnn.rnn_lst[0]
-            if (self.fuse_mix_scan and K <= 16 and B * cell0.n_out >= MIX_SCAN_MIN_COLS):
+            if (not grad and self.fuse_mix_scan and K <= 16 and B * cell0.n_out >= MIX_SCAN_MIN_COLS):
                 # enough columns to occupy the SIMDs: the scan lanes build U0 themselves
                 h0, c0_last = ops.mix_sru_fwd(A, Bt, P, Wp_f, cell0.bias, None, cell0.activation)
                 out, _ = self.mrnn(h0, tail=S, first_done=c0_last)
@@ -159,7 +167,10 @@ class BaseDMN(nn.Module):
             out = out.permute(1, 2, 0).contiguous().view(B, -1, H, W)
             if not self.high_res:
                 oc = self.output_collapse                              # dmn.py:213-214
-                out = ops.channel_dot(out, oc.weight.detach().view(-1), oc.bias.detach())
+                if grad:
+                    out = oc(out)
+                else:
+                    out = ops.channel_dot(out, oc.weight.detach().view(-1), oc.bias.detach())
             return out
 
         # comb_conv split by input block [vis+coords | WE | h | P]  (dmn.py:114-118,187-192)
@@ -185,9 +196,15 @@ class BaseDMN(nn.Module):
         U0 = q.W_fold + b_fold is assembled directly from the vis / language / P blocks and the
         (S*L, B, M) tensor Q and its 20.6 GMAC/sample GEMM are never needed (3.9 GMAC instead).
         Exact algebra, fp32 re-association only (~1e-6 relative; parity-tested).  Cached per
-        weight version; inference only (training keeps the unfused, autograd-friendly path)."""
+        weight version at inference; under autograd it is rebuilt as part of the graph."""
         Wc = self.comb_conv.weight
         W0 = self.mrnn.rnn_lst[0].weight
+        n_lang = self.emb_size + self.hid_size
+        if torch.is_grad_enabled():                                  # training: part of the graph, no cache
+            Wfold = Wc.view(Wc.shape[0], -1).t().mm(W0)
+            bfold = self.comb_conv.bias.view(1, -1).mm(W0).view(-1)
+            c8 = Wfold.shape[0] - n_lang - self.num_filters
+            return (Wfold[:c8], Wfold[c8:c8 + n_lang], Wfold[c8 + n_lang:].t().contiguous(), bfold)
         key = (Wc.data_ptr(), Wc._version, W0.data_ptr(), W0._version,
                self.comb_conv.bias._version, str(Wc.device))
         if self._fold_cache is None or self._fold_cache[0] != key:

@@ -100,11 +100,12 @@ def test_config5_scan_T4096_B128_d1000_split_in_time_and_column_subset_oracle():
 # ------------------------------------------------------------------------------------
 # configs[3]: gradients of the training step
 # ------------------------------------------------------------------------------------
-@pytest.mark.parametrize("hid_mixed,mix_we", [(16, True), (21, True), (21, False), (16, False)])
-def test_training_step_gradients_match_autograd_of_the_torch_oracle(hid_mixed, mix_we):
+@pytest.mark.parametrize("hid_mixed,mix_we,fold", [(16, True, True), (21, True, True), (21, False, True), (16, False, True),
+                                                   (21, True, False)])
+def test_training_step_gradients_match_autograd_of_the_torch_oracle(hid_mixed, mix_we, fold):
     """BaseDMN.hot_path -> bilinear upsample to the mask size -> BCEWithLogitsLoss (train.py:275-283)
     through the HIP forward + hand-written backward kernels (scan k = 3 and k = 4, dynamic filters,
-    concat-free mix) vs torch autograd of oracle/dmn_ref.hot_path (pure torch, reference-shaped).
+    concat-free mix -- with comb_conv folded into layer 0's projection for k = 4, and without) vs torch autograd of oracle/dmn_ref.hot_path (pure torch, reference-shaped).
     The loss and EVERY parameter's gradient (and the gradient w.r.t. the backbone features) within
     1e-4 relative."""
     cfg = dict(emb_size=16, hid_size=16, vis_size=32, num_filters=3, mixed_size=16,
@@ -114,6 +115,7 @@ def test_training_step_gradients_match_autograd_of_the_torch_oracle(hid_mixed, m
     state = det_fill_state(net.state_dict())
     torch.nn.Module.load_state_dict(net, state)
     net = net.to(DEV).train()
+    net.fold_in_training = fold       # k = 4 layer 0 (hid_mixed != mixed_size): comb_conv folded into its projection
     B, H, W, L = 2, 4, 3, 5
     vis = det_uniform((B, cfg["vis_size"], H, W), 601, 1.0).clamp_(min=0)
     lang = det_ints((B, L), 602, 50)
