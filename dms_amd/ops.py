@@ -78,23 +78,33 @@ def gemm_backend():
 GEMM_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning", "gemm_mi355x_512px.csv")
 
 
+GEMM_TABLE_TRAIN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning", "gemm_mi355x_train320.csv")
+
+
 def use_gemm_table(path=None):
-    """Opt in to a recorded per-shape solution table for the library GEMMs (PyTorch TunableOp in
-    look-up mode: no tuning at run time).  The table shipped in dms_amd/tuning/ was searched on
+    """Opt in to recorded per-shape solution tables for the library GEMMs (PyTorch TunableOp in
+    look-up mode: no tuning at run time).  The tables shipped in dms_amd/tuning/ were searched on
     one MI355X over all rocBLAS + hipBLASLt fp32 solutions for every GEMM shape of the B=32 and
-    the B=1 512 px inference step (tools/tune_gemms.py); shapes it does not hold keep the library's own
-    choice.  TunableOp ignores the file unless its validator lines (torch, HIP, rocBLAS,
-    hipBLASLt versions, gfx arch) match the running stack.  Process-global.  Returns the number
-    of entries loaded (0: file missing or rejected)."""
+    the B=1 512 px inference step (tools/tune_gemms.py) and of the B=64 320 px training step
+    (forward, dgrad, wgrad; tools/tune_train_gemms.py); shapes they do not hold keep the library's
+    own choice.  TunableOp ignores a file unless its validator lines (torch, HIP, rocBLAS,
+    hipBLASLt versions, gfx arch) match the running stack.  Process-global.  `path`: one file, or
+    several separated by os.pathsep (also DMN_GEMM_TABLE).  Returns the number of entries loaded
+    (0: files missing or rejected)."""
     import torch.cuda.tunable as tunable
-    path = path or os.environ.get("DMN_GEMM_TABLE", GEMM_TABLE)
-    if path in ("0", "off") or not os.path.exists(path):
+    path = path or os.environ.get("DMN_GEMM_TABLE", GEMM_TABLE + os.pathsep + GEMM_TABLE_TRAIN)
+    if path in ("0", "off"):
+        return 0
+    files = [p for p in path.split(os.pathsep) if p and os.path.exists(p)]
+    if not files:
         return 0
     tunable.enable(True)
     tunable.tuning_enable(False)
-    ok = tunable.read_file(path)
-    # TunableOp writes its results back to "its" file; keep that away from the shipped table
-    # (several ranks share it) by pointing it at a per-process scratch name
+    ok = False
+    for f in files:
+        ok = bool(tunable.read_file(f)) or ok
+    # TunableOp writes its results back to "its" file; keep that away from the shipped tables
+    # (several ranks share them) by pointing it at a per-process scratch name
     tunable.set_filename(os.path.join(tempfile.gettempdir(), "dmn_tunableop_unused_%d.csv" % os.getpid()))
     n = len(tunable.get_results()) if ok else 0
     if not n:
