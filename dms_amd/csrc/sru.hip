@@ -33,7 +33,7 @@ void launch_sru_fwd_k4(int act, bool store_c, int depth, dim3 grid, hipStream_t 
                        float *c_last, int T, int ncols, int d, float scale_x, int h_t0,
                        int chunk_len, const float2 *carries);
 void launch_sru_fwd_k2(int depth, dim3 grid, hipStream_t s, const float *U, const float *bias,
-                       const float *c0, float *c_last, int T, int ncols, int d);
+                       const float *c0, float *c_all, float *c_last, int T, int ncols, int d);
 constexpr int WHOLE_SEQUENCE = 0x7fffffff / 2;   // chunk_len of the un-chunked scan
 
 
@@ -155,19 +155,32 @@ extern "C" int dmn_sru_fwd(const float *U, const float *x, const float *bias, co
     return launch_status("dmn_sru_fwd");
 }
 
-extern "C" int dmn_sru_state_fwd(const float *U2, const float *bias, const float *c0,
-                                 float *c_last, int T, int B, int d, void *stream)
+static int state_fwd_impl(const char *fn, const float *U2, const float *bias, const float *c0, float *c_all,
+                          float *c_last, int T, int B, int d, void *stream)
 {
-    if ((!U2 && T > 0) || !bias || !c_last) return fail(-1, "dmn_sru_state_fwd: U2, bias and c_last must not be NULL");
-    if (T < 0 || B <= 0 || d <= 0) return fail(-4, "dmn_sru_state_fwd: bad sizes T=%d B=%d d=%d", T, B, d);
-    if ((long long)B * d * 2 * 4 * 33 >= 0x7fffffffLL) return fail(-5, "dmn_sru_state_fwd: B*d=%lld too large", (long long)B * d);
-    if ((uintptr_t)U2 & 7) return fail(-7, "dmn_sru_state_fwd: U2 must be 8-byte aligned");
+    if ((!U2 && T > 0) || !bias || !c_last) return fail(-1, "%s: U2, bias and c_last must not be NULL", fn);
+    if (T < 0 || B <= 0 || d <= 0) return fail(-4, "%s: bad sizes T=%d B=%d d=%d", fn, T, B, d);
+    if ((long long)B * d * 2 * 4 * 33 >= 0x7fffffffLL) return fail(-5, "%s: B*d=%lld too large", fn, (long long)B * d);
+    if ((uintptr_t)U2 & 7) return fail(-7, "%s: U2 must be 8-byte aligned", fn);
     const int ncols = B * d;
     const int nwaves = (ncols + WAVE - 1) / WAVE;
     int depth = depth_override();
-    if (depth <= 0) depth = pick_depth(nwaves, false);
-    launch_sru_fwd_k2(depth, dim3(nwaves), (hipStream_t)stream, U2, bias, c0, c_last, T, ncols, d);
-    return launch_status("dmn_sru_state_fwd");
+    if (depth <= 0) depth = pick_depth(nwaves, c_all != nullptr);
+    launch_sru_fwd_k2(depth, dim3(nwaves), (hipStream_t)stream, U2, bias, c0, c_all, c_last, T, ncols, d);
+    return launch_status(fn);
+}
+
+extern "C" int dmn_sru_state_fwd(const float *U2, const float *bias, const float *c0,
+                                 float *c_last, int T, int B, int d, void *stream)
+{
+    return state_fwd_impl("dmn_sru_state_fwd", U2, bias, c0, nullptr, c_last, T, B, d, stream);
+}
+
+extern "C" int dmn_sru_state_fwd_train(const float *U2, const float *bias, const float *c0, float *c_all,
+                                       float *c_last, int T, int B, int d, void *stream)
+{
+    if (!c_all && T > 0) return fail(-1, "dmn_sru_state_fwd_train: c_all must not be NULL");
+    return state_fwd_impl("dmn_sru_state_fwd_train", U2, bias, c0, c_all, c_last, T, B, d, stream);
 }
 
 namespace dmn {

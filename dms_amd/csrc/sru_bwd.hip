@@ -30,6 +30,9 @@ namespace dmn {
 template <int K> struct BSlot;
 template <> struct BSlot<4> { f32x4 u; float c, gh; };
 template <> struct BSlot<3> { f32x3 u; float x, c, gh; };
+// K = 2: the state-only steps of the last layer in training (no hidden state is read from them, so only
+// the cell-state chain carries gradient): U2 = [u0 | forget], no grad_h
+template <> struct BSlot<2> { f32x2 u; float c; };
 
 struct BwdSrds { i32x4 U, X, C, G; };
 
@@ -51,6 +54,13 @@ __device__ __forceinline__ void issue_bload(BSlot<3> &s, const BwdSrds r, unsign
     asm volatile("buffer_load_dword %0, %1, %2, %3 offen" DMN_LD_POLICY : "+v"(s.gh) : "v"(offX), "s"(r.G), "s"(sX) : "memory");
 }
 
+__device__ __forceinline__ void issue_bload(BSlot<2> &s, const BwdSrds r, unsigned offU, unsigned offX,
+                                            unsigned sU, unsigned sX)
+{
+    asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" DMN_LD_POLICY : "+v"(s.u) : "v"(offU), "s"(r.U), "s"(sU) : "memory");
+    asm volatile("buffer_load_dword %0, %1, %2, %3 offen" DMN_LD_POLICY : "+v"(s.c) : "v"(offX), "s"(r.C), "s"(sX) : "memory");
+}
+
 // wait until at most N younger VMEM operations are outstanding; naming the slot "+v" makes every
 // consumer of the slot depend on this statement
 template <int N>
@@ -64,6 +74,12 @@ __device__ __forceinline__ void wait_bslot(BSlot<3> &s)
 {
     constexpr int n = N > 63 ? 63 : N;
     asm volatile("s_waitcnt vmcnt(%4)" : "+v"(s.u), "+v"(s.x), "+v"(s.c), "+v"(s.gh) : "n"(n) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_bslot(BSlot<2> &s)
+{
+    constexpr int n = N > 63 ? 63 : N;
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(s.u), "+v"(s.c) : "n"(n) : "memory");
 }
 
 // The wide gradient stores go out as inline asm WITH two wait states attached.  gfx950 reads the data
@@ -80,6 +96,11 @@ __device__ __forceinline__ void wait_bslot(BSlot<3> &s)
 __device__ __forceinline__ void store_wide(u32x4 o, i32x4 srd, unsigned off, unsigned soff)
 {
     asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt" DMN_BWD_STORE_NOP :: "v"(o), "v"(off), "s"(srd), "s"(soff) : "memory");
+}
+// 64-bit store (K = 2): its data is read with the address, no wait states needed
+__device__ __forceinline__ void store_pair(u32x2 o, i32x4 srd, unsigned off, unsigned soff)
+{
+    asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen nt" :: "v"(o), "v"(off), "s"(srd), "s"(soff) : "memory");
 }
 __device__ __forceinline__ void store_wide(u32x3 o, i32x4 srd, unsigned off, unsigned soff)
 {
@@ -99,7 +120,7 @@ sru_bwd_cols(const float *__restrict__ U, const float *__restrict__ x,
              float *__restrict__ grad_bias, float *__restrict__ grad_c0,
              int T, int ncols, int d, float scale_x)
 {
-    constexpr int NLD = (K == 3) ? 4 : 3;      // VMEM loads per step
+    constexpr int NLD = (K == 3) ? 4 : (K == 4 ? 3 : 2);      // VMEM loads per step
     constexpr int NST = DMN_VMCNT_COUNT_STORES ? ((K == 3) ? 2 : 1) : 0;   // VMEM stores per step that a wait may leave outstanding (sru_ring.h)
     const int col = blockIdx.x * WAVE + threadIdx.x;
     if (col >= ncols) return;
@@ -153,7 +174,10 @@ sru_bwd_cols(const float *__restrict__ U, const float *__restrict__ x,
         auto finish = [&](float cprev, i32x4 rGU, rsrc_t rGX, unsigned sU, unsigned sX) {
             const float gg1 = pend.gc * (cprev - pend.u0) * pend.dg1;
             gb1 += gg1;
-            if (K == 4) {
+            if constexpr (K == 2) {
+                const u32x2 o = {__float_as_uint(pend.gu0), __float_as_uint(gg1)};
+                store_pair(o, rGU, offU, sU);
+            } else if (K == 4) {
                 const u32x4 o = {__float_as_uint(pend.gu0), __float_as_uint(gg1), __float_as_uint(pend.gg2),
                                  __float_as_uint(pend.gxp)};
                 store_wide(o, rGU, offU, sU);
@@ -165,6 +189,16 @@ sru_bwd_cols(const float *__restrict__ U, const float *__restrict__ x,
         };
         // step t up to the point where c_{t-1} is needed
         auto compute = [&](const BSlot<K> &s) {
+            if constexpr (K == 2) {
+                // c = (c' - u0) * g1 + u0 is all there is: dL/dc arrives from the later steps only
+                const float g1 = fast_rcp(1.0f + fast_exp2(__builtin_fmaf(s.u.y, -LOG2E, bf2)));
+                pend.gc = cur;
+                pend.gu0 = pend.gc * (1.0f - g1);
+                pend.dg1 = g1 * (1.0f - g1);
+                asm volatile("v_mov_b32 %0, %1" : "=v"(pend.u0) : "v"(s.u.x));
+                cur = pend.gc * g1;
+                return;
+            } else {
             const float g1 = fast_rcp(1.0f + fast_exp2(__builtin_fmaf(s.u.y, -LOG2E, bf2)));
             const float g2 = fast_rcp(1.0f + fast_exp2(__builtin_fmaf(s.u.z, -LOG2E, br2)));
             const float cval = act_fwd<ACT>(s.c);
@@ -184,6 +218,7 @@ sru_bwd_cols(const float *__restrict__ U, const float *__restrict__ x,
             // registers whose loads are still in flight (caught by tools/check_asm_waits.py).
             asm volatile("v_mov_b32 %0, %1" : "=v"(pend.u0) : "v"(s.u.x));
             cur = pend.gc * g1;
+            }
         };
 
         // prologue: DEPTH steps in flight (times T-1 .. T-DEPTH)
@@ -266,7 +301,7 @@ sru_bwd_cols(const float *__restrict__ U, const float *__restrict__ x,
     }
     // batch reduction of the bias gradient: one hardware float atomic per lane and gate
     unsafeAtomicAdd(grad_bias + j, gb1);
-    unsafeAtomicAdd(grad_bias + d + j, gb2);
+    if (K != 2) unsafeAtomicAdd(grad_bias + d + j, gb2);
     grad_c0[col] = cur;
 }
 
@@ -288,6 +323,36 @@ static void launch_bwd_act(int act, dim3 grid, hipStream_t s, const float *U, co
 }  // namespace dmn
 
 using namespace dmn;
+
+extern "C" int dmn_sru_state_bwd(const float *U2, const float *bias, const float *c0, const float *c_all,
+                                 const float *grad_last, float *grad_U2, float *grad_bias_f, float *grad_c0,
+                                 int T, int B, int d, void *stream)
+{
+    const char *fn = "dmn_sru_state_bwd";
+    if ((!U2 && T > 0) || !bias || !grad_bias_f || !grad_c0) return fail(-1, "%s: NULL pointer", fn);
+    if (T < 0 || B <= 0 || d <= 0) return fail(-4, "%s: bad sizes T=%d B=%d d=%d", fn, T, B, d);
+    if ((long long)B * d * 2 * 4 * 34 >= 0x7fffffffLL) return fail(-5, "%s: B*d=%lld too large", fn, (long long)B * d);
+    if ((!c_all || !grad_U2) && T > 0) return fail(-1, "%s: c_all and grad_U2 must not be NULL", fn);
+    if (((uintptr_t)U2 | (uintptr_t)grad_U2) & 7) return fail(-7, "%s: U2 and grad_U2 must be 8-byte aligned", fn);
+    const int ncols = B * d;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(grad_bias_f, 0, sizeof(float) * (size_t)d, s);
+    if (e != hipSuccess) return fail((int)e, "%s: hipMemsetAsync(grad_bias_f): %s", fn, hipGetErrorString(e));
+    const char *env = getenv("DMN_SRU_BWD_DEPTH");
+    int depth = env ? atoi(env) : 0;
+    if (depth <= 0) depth = 6;
+    dim3 grid((ncols + WAVE - 1) / WAVE);
+    // K = 2 reads bias[j] (forget) only; grad_bias_f has d entries (the reset half has no gradient here)
+#define DMN_SB(DV) hipLaunchKernelGGL((sru_bwd_cols<2, DMN_ACT_IDENTITY, DV>), grid, dim3(WAVE), 0, s, U2, (const float *)nullptr, bias, c0, c_all, \
+                                      (const float *)nullptr, grad_last, grad_U2, (float *)nullptr, grad_bias_f, grad_c0, T, ncols, d, 1.0f)
+    if (depth <= 3) DMN_SB(3);
+    else if (depth <= 4) DMN_SB(4);
+    else if (depth <= 6) DMN_SB(6);
+    else if (depth <= 8) DMN_SB(8);
+    else DMN_SB(16);
+#undef DMN_SB
+    return launch_status(fn);
+}
 
 extern "C" int dmn_sru_bwd(const float *U, const float *x, const float *bias, const float *c0,
                            const float *c_all, const float *grad_h, const float *grad_last,

@@ -281,10 +281,15 @@ static void launch_fwd_act(int act, int depth, dim3 grid, hipStream_t s, const f
 #if DMN_SRU_K == 2
 // state-only: no h, no c_all, the activation is never applied; the caller passes h_t0 = T
 void DMN_SRU_LAUNCH_NAME(int depth, dim3 grid, hipStream_t s, const float *U, const float *bias,
-                         const float *c0, float *c_last, int T, int ncols, int d)
+                         const float *c0, float *c_all, float *c_last, int T, int ncols, int d)
 {
-    launch_fwd<2, DMN_ACT_IDENTITY, false>(depth, grid, s, U, nullptr, bias, c0, nullptr, nullptr,
-                                           c_last, T, ncols, d, 1.0f, T, 0x7fffffff / 2, nullptr);
+    // c_all != NULL (training): every step's cell state is kept for the backward scan
+    if (c_all)
+        launch_fwd<2, DMN_ACT_IDENTITY, true>(depth, grid, s, U, nullptr, bias, c0, nullptr, c_all,
+                                              c_last, T, ncols, d, 1.0f, T, 0x7fffffff / 2, nullptr);
+    else
+        launch_fwd<2, DMN_ACT_IDENTITY, false>(depth, grid, s, U, nullptr, bias, c0, nullptr, nullptr,
+                                               c_last, T, ncols, d, 1.0f, T, 0x7fffffff / 2, nullptr);
 }
 #else
 void DMN_SRU_LAUNCH_NAME(int act, bool store_c, int depth, dim3 grid, hipStream_t s, const float *U,

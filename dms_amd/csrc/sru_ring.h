@@ -37,6 +37,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 using rsrc_t = __amdgpu_buffer_rsrc_t;
 
 __device__ __forceinline__ rsrc_t make_rsrc(const void *base)

@@ -237,6 +237,48 @@ def sru_state(u2, bias, c0=None, nchunks=None):
     return c_last
 
 
+class _SRUStateCompute(torch.autograd.Function):
+    """Autograd node of the state-only scan: c_last from u2 = [u0 | forget] (training: the steps of the
+    last mSRU layer whose hidden state nothing reads, so only the cell-state chain carries gradient)."""
+
+    @staticmethod
+    def forward(ctx, u2, bias, c0):
+        T, B, d, _ = u2.shape
+        with torch.cuda.device(u2.device):
+            c_all = torch.empty((T, B, d), device=u2.device, dtype=torch.float32)
+            c_last = torch.empty((B, d), device=u2.device, dtype=torch.float32)
+            _lib.call("dmn_sru_state_fwd_train", _ptr(u2), _ptr(bias), _ptr(c0), _ptr(c_all), _ptr(c_last),
+                      T, B, d, _stream())
+        ctx.save_for_backward(u2, bias, c0, c_all)
+        return c_last
+
+    @staticmethod
+    def backward(ctx, grad_last):
+        u2, bias, c0, c_all = ctx.saved_tensors
+        T, B, d, _ = u2.shape
+        grad_last = grad_last.contiguous()
+        with torch.cuda.device(u2.device):
+            gu2 = torch.empty_like(u2)
+            gbf = torch.empty((d,), device=u2.device, dtype=torch.float32)
+            gc0 = torch.empty((B, d), device=u2.device, dtype=torch.float32)
+            _lib.call("dmn_sru_state_bwd", _ptr(u2), _ptr(bias), _ptr(c0), _ptr(c_all), _ptr(grad_last),
+                      _ptr(gu2), _ptr(gbf), _ptr(gc0), T, B, d, _stream())
+        gbias = torch.cat([gbf, torch.zeros_like(gbf)]) if ctx.needs_input_grad[1] else None
+        return gu2, gbias, (gc0 if c0 is not None and ctx.needs_input_grad[2] else None)
+
+
+def sru_state_train(u2, bias, c0=None):
+    """sru_state under autograd: c_last (B, d) with gradients to u2 (T, B, d, 2), bias (2d) and c0."""
+    T, B, d, two = u2.shape
+    if two != 2:
+        raise RuntimeError("dms_amd.sru_state_train: expected (T, B, d, 2), got %s" % (tuple(u2.shape),))
+    u2 = u2.contiguous()
+    _chk("sru_state_train", u2)
+    _chk("sru_state_train", bias, (2 * d,))
+    _chk("sru_state_train", c0, (B, d) if c0 is not None else None)
+    return _SRUStateCompute.apply(u2, bias, c0.contiguous() if c0 is not None else None)
+
+
 class _SRUCompute(torch.autograd.Function):
     """Autograd node of the scan (the role of upstream's SRU_Compute)."""
 

@@ -31,6 +31,7 @@ class SRUCell(nn.Module):
         self.weight = nn.Parameter(torch.empty(n_in, n_out * self.k))
         self.bias = nn.Parameter(torch.empty(n_out * 2))
         self.state_only_head = True     # inference shortcut of _forward_tail; False = one full scan
+        self.state_only_head_in_training = True   # the same under autograd (round 2)
         self.init_weight()
 
     def init_weight(self):
@@ -91,6 +92,17 @@ class SRUCell(nn.Module):
             or (c0 is not None and c0.requires_grad))
         if 0 < h_t0 < T and not needs_grad and self.state_only_head:
             return self._forward_tail(x, c0, h_t0)
+        if needs_grad and 0 < h_t0 < T and self.state_only_head_in_training:
+            # training, hidden states wanted from step h_t0 on only: the earlier steps reach the loss
+            # through the cell state alone, so they -- and their dgrad / wgrad GEMMs -- run on the
+            # [u0 | forget] weight columns only (2 of k), with the state-only scan's own backward
+            w01 = self.weight.view(self.n_in, self.n_out, self.k)[:, :, :2].reshape(self.n_in, -1)
+            u2 = x[:h_t0].reshape(h_t0 * B, n_in).mm(w01).view(h_t0, B, self.n_out, 2)
+            c_mid = ops.sru_state_train(u2, self.bias, c0)
+            tail = x[h_t0:]
+            u = tail.reshape((T - h_t0) * B, n_in).mm(self.weight).view(T - h_t0, B, self.n_out, self.k)
+            return ops.sru_compute(u, tail if self.k == 3 else None, self.bias, c_mid,
+                                   self.activation, self.scale_x, 0)
         if needs_grad:
             u = x.view(T * B, n_in).mm(self.weight)
         else:                                   # inference: BLAS library chosen per shape

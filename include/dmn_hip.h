@@ -97,6 +97,19 @@ int dmn_sru_fwd_scan_noalloc(const float *U, const float *x, const float *bias, 
  */
 int dmn_sru_state_fwd(const float *U2, const float *bias, const float *c0, float *c_last,
                       int T, int B, int d, void *stream);
+/*
+ * The same under autograd (the training step: `SRU_Compute.forward/backward` of the last mSRU layer's
+ * first T - H*W steps, dmn.py:204,209): the forward also keeps every step's cell state,
+ *   c_all (T, B, d);
+ * the backward takes dL/dc_last (grad_last (B, d) or NULL = 0) and returns
+ *   grad_U2 (T, B, d, 2), grad_bias_f (d) = the forget half of the bias gradient (summed over time and
+ *   batch in the kernel; the reset half is zero for these steps), grad_c0 (B, d).
+ */
+int dmn_sru_state_fwd_train(const float *U2, const float *bias, const float *c0, float *c_all,
+                            float *c_last, int T, int B, int d, void *stream);
+int dmn_sru_state_bwd(const float *U2, const float *bias, const float *c0, const float *c_all,
+                      const float *grad_last, float *grad_U2, float *grad_bias_f, float *grad_c0,
+                      int T, int B, int d, void *stream);
 /* time-parallel variant for FEW columns (batch-1 serving), as dmn_sru_fwd_scan is to dmn_sru_fwd:
  * chunk aggregates (prod f, c | c_in = 0) composed in time order; `workspace` holds
  * dmn_sru_scan_workspace_floats(T, B, d, nchunks) floats, caller-owned, 8-byte aligned. */

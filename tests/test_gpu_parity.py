@@ -146,6 +146,62 @@ def test_sru_bwd_every_ring_depth_and_sequence_length(depth, T, monkeypatch):
             np.testing.assert_allclose(xg.grad.cpu().numpy(), gx_r, rtol=2e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("depth", ["3", "4", "6", "8", "16"])
+@pytest.mark.parametrize("T", [1, 2, 5, 16, 37, 48])
+def test_sru_state_scan_backward_matches_the_full_scan_backward(depth, T, monkeypatch):
+    """Training form of the state-only scan (dmn_sru_state_fwd_train / dmn_sru_state_bwd, k = 2 ring):
+    c_last bit-identical to the full k = 3 scan's, and the gradients w.r.t. [u0 | forget], the forget
+    bias and c0 equal those of the full scan when nothing reads its hidden states (grad_h = 0), at every
+    ring depth and for T below / at / above a multiple of it."""
+    monkeypatch.setenv("DMN_SRU_BWD_DEPTH", depth)
+    B, d, k = 2, 70, 3
+    u, x, bias, c0 = _case(T, B, d, k, 163)
+    gl = det_uniform((B, d), 165, 1.0)
+    ug, bg, cg = (_g(t).requires_grad_(True) for t in (u, bias, c0))
+    h, c_full = ops.sru_compute(ug, _g(x), bg, cg, "tanh", 1.0)
+    (c_full * _g(gl)).sum().backward()
+    u2 = _g(u)[..., :2].contiguous().requires_grad_(True)
+    b2, c2 = _g(bias).requires_grad_(True), _g(c0).requires_grad_(True)
+    c_state = ops.sru_state_train(u2, b2, c2)
+    assert torch.equal(c_state, c_full)
+    (c_state * _g(gl)).sum().backward()
+    np.testing.assert_allclose(u2.grad.cpu().numpy(), ug.grad[..., :2].cpu().numpy(), rtol=1e-5, atol=1e-6)
+    assert float(ug.grad[..., 2].abs().max()) == 0.0              # the reset column carries no gradient here
+    np.testing.assert_allclose(b2.grad[:d].cpu().numpy(), bg.grad[:d].cpu().numpy(), rtol=1e-4, atol=1e-5)
+    assert float(b2.grad[d:].abs().max()) == 0.0
+    np.testing.assert_allclose(c2.grad.cpu().numpy(), cg.grad.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    # without c0
+    u3 = _g(u)[..., :2].contiguous().requires_grad_(True)
+    c_n = ops.sru_state_train(u3, _g(bias), None)
+    (c_n * _g(gl)).sum().backward()
+    assert torch.equal(c_n, ops.sru_forward_raw(_g(u), _g(x), _g(bias), None, "tanh", 1.0, nchunks=1)[2])
+    assert bool(torch.isfinite(u3.grad).all())
+
+
+@pytest.mark.parametrize("n_in,n_out,T,tail", [(10, 10, 37, 5), (12, 10, 37, 5), (10, 10, 6, 5), (16, 16, 64, 1)])
+def test_sru_module_tail_training_shortcut_equals_the_plain_autograd_path(n_in, n_out, T, tail):
+    """SRU(..., tail=n) under autograd: the last layer's first T - n steps run on the [u0 | forget] columns
+    with the state-only scan (SRUCell.state_only_head_in_training); output and EVERY gradient equal the
+    plain path's (one full scan per layer) to rounding."""
+    B = 3
+    x = det_uniform((T, B, n_in), 171, 1.0)
+    g = det_uniform((tail, B, n_out), 172, 1.0)
+    got = {}
+    for flag in (True, False):
+        rnn = dms_amd.SRU(n_in, n_out, num_layers=3)
+        rnn.load_state_dict(det_fill_state(rnn.state_dict()))
+        rnn = rnn.to(DEV)
+        for cell in rnn.rnn_lst:
+            cell.state_only_head_in_training = flag
+        xg = x.to(DEV).requires_grad_(True)
+        out, c = rnn(xg, tail=tail)
+        assert out.shape == (tail, B, n_out)
+        ((out * g.to(DEV)).sum() + c.sum()).backward()
+        got[flag] = [out.detach().cpu(), xg.grad.cpu()] + [p.grad.cpu() for p in rnn.parameters()]
+    for a, b in zip(got[True], got[False]):
+        assert rel_err(a, b) < 1e-5
+
+
 @pytest.mark.parametrize("T,B,d", [(1, 1, 5), (7, 3, 5), (33, 2, 70), (300, 2, 1005), (64, 1, 64)])
 @pytest.mark.parametrize("k", [3, 4])
 def test_sru_state_only_scan_is_bit_identical_to_full_scan_and_matches_oracle(T, B, d, k):
