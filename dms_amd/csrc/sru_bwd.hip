@@ -12,6 +12,9 @@
 // at every loop header).  Per (t, b, j): read 4k (U) + 4 (x, k = 3) + 4 (c) + 4 (grad_h), write
 // 4k (grad_U) + 4 (grad_x, k = 3) = 40 B for k = 3 and for k = 4.
 //
+// k = 2 is the state-only variant (steps whose hidden state nothing reads: [u0 | forget] columns, no grad_h,
+// 8 + 4 B read and 8 B written per element; dmn_sru_state_bwd).
+//
 // Two things differ from the forward:
 //  * the step for time t needs c_{t-1}, which arrives with the NEXT ring slot.  The loop is
 //    therefore skewed by one step: slot(t) is waited for, its c finishes the PENDING step t+1
@@ -189,27 +192,22 @@ sru_bwd_cols(const float *__restrict__ U, const float *__restrict__ x,
         };
         // step t up to the point where c_{t-1} is needed
         auto compute = [&](const BSlot<K> &s) {
-            if constexpr (K == 2) {
-                // c = (c' - u0) * g1 + u0 is all there is: dL/dc arrives from the later steps only
-                const float g1 = fast_rcp(1.0f + fast_exp2(__builtin_fmaf(s.u.y, -LOG2E, bf2)));
-                pend.gc = cur;
-                pend.gu0 = pend.gc * (1.0f - g1);
-                pend.dg1 = g1 * (1.0f - g1);
-                asm volatile("v_mov_b32 %0, %1" : "=v"(pend.u0) : "v"(s.u.x));
-                cur = pend.gc * g1;
-                return;
-            } else {
             const float g1 = fast_rcp(1.0f + fast_exp2(__builtin_fmaf(s.u.y, -LOG2E, bf2)));
-            const float g2 = fast_rcp(1.0f + fast_exp2(__builtin_fmaf(s.u.z, -LOG2E, br2)));
-            const float cval = act_fwd<ACT>(s.c);
-            float xv;
-            if constexpr (K == 3) xv = s.x * sx; else xv = s.u.w;
-            // h = (act(c) - x') * g2 + x'
-            pend.gxp = s.gh * (1.0f - g2);
-            pend.gg2 = s.gh * (cval - xv) * (g2 * (1.0f - g2));
-            gb2 += pend.gg2;
+            if constexpr (K == 2) {
+                // state-only steps: dL/dc arrives from the later steps alone
+                pend.gc = cur;
+            } else {
+                const float g2 = fast_rcp(1.0f + fast_exp2(__builtin_fmaf(s.u.z, -LOG2E, br2)));
+                const float cval = act_fwd<ACT>(s.c);
+                float xv;
+                if constexpr (K == 3) xv = s.x * sx; else xv = s.u.w;
+                // h = (act(c) - x') * g2 + x'
+                pend.gxp = s.gh * (1.0f - g2);
+                pend.gg2 = s.gh * (cval - xv) * (g2 * (1.0f - g2));
+                gb2 += pend.gg2;
+                pend.gc = __builtin_fmaf(s.gh * g2, act_bwd<ACT>(cval), cur);
+            }
             // c = (c' - u0) * g1 + u0
-            pend.gc = __builtin_fmaf(s.gh * g2, act_bwd<ACT>(cval), cur);
             pend.gu0 = pend.gc * (1.0f - g1);
             pend.dg1 = g1 * (1.0f - g1);
             // u0 outlives the slot's reload: move it OUT of the slot's register tuple with a real
@@ -218,7 +216,6 @@ sru_bwd_cols(const float *__restrict__ U, const float *__restrict__ x,
             // registers whose loads are still in flight (caught by tools/check_asm_waits.py).
             asm volatile("v_mov_b32 %0, %1" : "=v"(pend.u0) : "v"(s.u.x));
             cur = pend.gc * g1;
-            }
         };
 
         // prologue: DEPTH steps in flight (times T-1 .. T-DEPTH)
