@@ -105,12 +105,16 @@ static int depth_override()
 //    64.4 % at 6 -- more rows in flight only compete with the stores in the memory system;
 //  * read-mostly launches (state-only scan, the last layer's tail call) want all the depth they can
 //    get: 89 % at depth 32 vs 77 % at 16 and 48 % at 8 on 503 waves.
-static int pick_depth(int nwaves, bool stores_every_step)
+//  * a wait also covers the stores issued since the slot's load; the k = 4 training scan (ONE load, TWO
+//    stores per step: h and c) needs twice the slots for the same loads in flight: 1005 waves depth 16 =
+//    73.2 % vs 71.7 % at 8 (the other variants measured best at the unscaled depth).
+static int pick_depth(int nwaves, bool stores_every_step, int loads = 2, int stores = 1)
 {
     if (!stores_every_step)
         return (nwaves <= 3 * NUM_CU) ? 32 : (nwaves <= 6 * NUM_CU ? 16 : 8);
     if (nwaves >= 6 * NUM_CU) return 3;
-    const double raw = 8.0e6 / ((double)nwaves * WAVE * 16.0);          // 16 B loaded per column and step
+    const double per_load = (loads == 1 && stores == 2) ? 2.0 : 1.0;
+    const double raw = per_load * 8.0e6 / ((double)nwaves * WAVE * 16.0);   // 16 B loaded per column and step
     static const int cand[] = {3, 4, 6, 8, 16, 24, 32};
     int best = cand[0];
     for (int c : cand)
@@ -147,7 +151,7 @@ extern "C" int dmn_sru_fwd(const float *U, const float *x, const float *bias, co
     const int ncols = B * d;
     const int nwaves = (ncols + WAVE - 1) / WAVE;
     int depth = depth_override();
-    if (depth <= 0) depth = pick_depth(nwaves, c_all != nullptr || 2 * (long long)h_t0 < T);
+    if (depth <= 0) depth = pick_depth(nwaves, c_all != nullptr || 2 * (long long)h_t0 < T, k == 3 ? 2 : 1, c_all ? 2 : 1);
     dim3 grid(nwaves);
     hipStream_t s = (hipStream_t)stream;
     if (k == 3) launch_sru_fwd_k3(act, c_all != nullptr, depth, grid, s, U, x, bias, c0, h, c_all, c_last, T, ncols, d, scale_x, h_t0, WHOLE_SEQUENCE, nullptr);
@@ -165,7 +169,7 @@ static int state_fwd_impl(const char *fn, const float *U2, const float *bias, co
     const int ncols = B * d;
     const int nwaves = (ncols + WAVE - 1) / WAVE;
     int depth = depth_override();
-    if (depth <= 0) depth = pick_depth(nwaves, c_all != nullptr);
+    if (depth <= 0) depth = pick_depth(nwaves, c_all != nullptr, 1, 1);
     launch_sru_fwd_k2(depth, dim3(nwaves), (hipStream_t)stream, U2, bias, c0, c_all, c_last, T, ncols, d);
     return launch_status(fn);
 }
