@@ -108,13 +108,13 @@ static int depth_override()
 //  * a wait also covers the stores issued since the slot's load; the k = 4 training scan (ONE load, TWO
 //    stores per step: h and c) needs twice the slots for the same loads in flight: 1005 waves depth 16 =
 //    73.2 % vs 71.7 % at 8 (the other variants measured best at the unscaled depth).
-static int pick_depth(int nwaves, bool stores_every_step, int loads = 2, int stores = 1)
+static int pick_depth(int nwaves, bool stores_every_step, int loads = 2, int stores = 1, double load_bytes = 16.0)
 {
     if (!stores_every_step)
         return (nwaves <= 3 * NUM_CU) ? 32 : (nwaves <= 6 * NUM_CU ? 16 : 8);
     if (nwaves >= 6 * NUM_CU) return 3;
     const double per_load = (loads == 1 && stores == 2) ? 2.0 : 1.0;
-    const double raw = per_load * 8.0e6 / ((double)nwaves * WAVE * 16.0);   // 16 B loaded per column and step
+    const double raw = per_load * 8.0e6 / ((double)nwaves * WAVE * load_bytes);   // bytes loaded per column and step
     static const int cand[] = {3, 4, 6, 8, 16, 24, 32};
     int best = cand[0];
     for (int c : cand)
@@ -169,7 +169,9 @@ static int state_fwd_impl(const char *fn, const float *U2, const float *bias, co
     const int ncols = B * d;
     const int nwaves = (ncols + WAVE - 1) / WAVE;
     int depth = depth_override();
-    if (depth <= 0) depth = pick_depth(nwaves, c_all != nullptr, 1, 1);
+    // k = 2 loads 8 B per step: twice the slots for the same bytes in flight (1005 waves, c stored: depth 16 =
+    // 78.7 % of 8 TB/s vs 60 % at 8; tools/state_train_bench.py)
+    if (depth <= 0) depth = pick_depth(nwaves, c_all != nullptr, 1, 1, 8.0);
     launch_sru_fwd_k2(depth, dim3(nwaves), (hipStream_t)stream, U2, bias, c0, c_all, c_last, T, ncols, d);
     return launch_status(fn);
 }

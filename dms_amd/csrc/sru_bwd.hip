@@ -337,7 +337,7 @@ extern "C" int dmn_sru_state_bwd(const float *U2, const float *bias, const float
     if (e != hipSuccess) return fail((int)e, "%s: hipMemsetAsync(grad_bias_f): %s", fn, hipGetErrorString(e));
     const char *env = getenv("DMN_SRU_BWD_DEPTH");
     int depth = env ? atoi(env) : 0;
-    if (depth <= 0) depth = 6;
+    if (depth <= 0) depth = 8;   // tools/state_train_bench.py, 1005 waves: 76.2 % of 8 TB/s at 8, 71 % at 6, 74 % at 16
     dim3 grid((ncols + WAVE - 1) / WAVE);
     // K = 2 reads bias[j] (forget) only; grad_bias_f has d entries (the reset half has no gradient here)
 #define DMN_SB(DV) hipLaunchKernelGGL((sru_bwd_cols<2, DMN_ACT_IDENTITY, DV>), grid, dim3(WAVE), 0, s, U2, (const float *)nullptr, bias, c0, c_all, \
