@@ -71,33 +71,62 @@ mix_fwd_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
             const float *Bp = Bt + ((long long)t * B + b) * M + m;
             if (VEC == 4) { const float4 v = *reinterpret_cast<const float4 *>(Bp); bt[0] = v.x; bt[1] = v.y; bt[2] = v.z; bt[3] = v.w; }
             else bt[0] = Bp[0];
+            if (KREG) {
+                // all PT pixels of a word advance together: one filter's PT responses are adjacent in LDS
+                // (16-byte broadcast reads instead of PT 4-byte ones); per output the k order is unchanged
+                float q[PT][VEC];
 #pragma unroll
-            for (int pp = 0; pp < PT; ++pp) {
-                const int s = s0 + pp;
-                float q[VEC];
+                for (int pp = 0; pp < PT; ++pp)
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) q[e] = a[pp][e] + bt[e];
-                if (KREG) {
+                    for (int e = 0; e < VEC; ++e) q[pp][e] = a[pp][e] + bt[e];
 #pragma unroll
-                    for (int k = 0; k < KR; ++k) {
-                        if (k < K) {
-                            const float pv = Ps[(t * K + k) * PT + pp];
+                for (int k = 0; k < KR; ++k) {
+                    if (k < K) {
+                        float pv[PT];
+                        const float *pr = Ps + (t * K + k) * PT;
+                        if (PT % 4 == 0) {
 #pragma unroll
-                            for (int e = 0; e < VEC; ++e) q[e] = __builtin_fmaf(w[e][k], pv, q[e]);
+                            for (int p4 = 0; p4 < PT / 4; ++p4) {
+                                const float4 v = *reinterpret_cast<const float4 *>(pr + 4 * p4);
+                                pv[4 * p4] = v.x; pv[4 * p4 + 1] = v.y; pv[4 * p4 + 2] = v.z; pv[4 * p4 + 3] = v.w;
+                            }
+                        } else {
+#pragma unroll
+                            for (int pp = 0; pp < PT; ++pp) pv[pp] = pr[pp];
                         }
+#pragma unroll
+                        for (int pp = 0; pp < PT; ++pp)
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) q[pp][e] = __builtin_fmaf(w[e][k], pv[pp], q[pp][e]);
                     }
-                } else {
+                }
+#pragma unroll
+                for (int pp = 0; pp < PT; ++pp) {
+                    const int s = s0 + pp;
+                    if (s < S) {
+                        float *Qp = Q + (((long long)s * L + t) * B + b) * M + m;
+                        if (VEC == 4) *reinterpret_cast<float4 *>(Qp) = make_float4(q[pp][0], q[pp][1], q[pp][2], q[pp][VEC - 1]);
+                        else Qp[0] = q[pp][0];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int pp = 0; pp < PT; ++pp) {
+                    const int s = s0 + pp;
+                    float q[VEC];
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) q[e] = a[pp][e] + bt[e];
                     for (int k = 0; k < K; ++k) {
                         const float pv = Ps[(t * K + k) * PT + pp];
 #pragma unroll
                         for (int e = 0; e < VEC; ++e)
                             q[e] = __builtin_fmaf(Wp[(long long)(m + e) * ldw + k], pv, q[e]);
                     }
-                }
-                if (s < S) {
-                    float *Qp = Q + (((long long)s * L + t) * B + b) * M + m;
-                    if (VEC == 4) *reinterpret_cast<float4 *>(Qp) = make_float4(q[0], q[1], q[2], q[VEC - 1]);
-                    else Qp[0] = q[0];
+                    if (s < S) {
+                        float *Qp = Q + (((long long)s * L + t) * B + b) * M + m;
+                        if (VEC == 4) *reinterpret_cast<float4 *>(Qp) = make_float4(q[0], q[1], q[2], q[VEC - 1]);
+                        else Qp[0] = q[0];
+                    }
                 }
             }
         }
