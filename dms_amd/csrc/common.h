@@ -57,6 +57,22 @@ __device__ __forceinline__ float act_fwd(float v)
     return v;
 }
 
+// act_fwd split in two halves with act_fwd(v) == act_back<ACT>(act_front<ACT>(v)) bit for bit: for tanh the
+// exponential and the reciprocal land on different sides (mix_sru_pair_kernel balances its two waves'
+// quarter-rate instructions this way), for relu / identity the front half is the whole activation.
+template <int ACT>
+__device__ __forceinline__ float act_front(float v)
+{
+    if (ACT == DMN_ACT_TANH) return 1.0f + fast_exp2(v * -2.8853900817779268f);
+    return act_fwd<ACT>(v);
+}
+template <int ACT>
+__device__ __forceinline__ float act_back(float v)
+{
+    if (ACT == DMN_ACT_TANH) return __builtin_fmaf(2.0f, fast_rcp(v), -1.0f);
+    return v;
+}
+
 // derivative expressed through the activation OUTPUT y
 template <int ACT>
 __device__ __forceinline__ float act_bwd(float y)

@@ -199,7 +199,9 @@ mix_sru_fwd_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
 // The single-wave kernel above is bound by one wave's in-order issue (~280 cycles per step) while
 // half of the 1024 SIMDs idle (512 waves at B = 32).  The cell state needs only the gates (u0,
 // forget); the hidden state needs (reset, highway) and act(c_t).  So a 128-thread workgroup runs
-//   wave 0 ("state"):  q01 = A.xy + Bt.xy + sum_k Wp01[k] P[t,k]  ->  f, c_t, act(c_t)  ->  LDS
+//   wave 0 ("state"):  q01 = A.xy + Bt.xy + sum_k Wp01[k] P[t,k]  ->  f, c_t, front half of act(c_t) -> LDS
+//                      (tanh = 2 / (1 + 2^(-2c log2 e)) - 1: the exponential here, the reciprocal over there,
+//                      three quarter-rate instructions per step on either side instead of four and two)
 //   wave 1 ("output"): q23 = A.zw + Bt.zw + sum_k Wp23[k] P[t,k]  ->  r, h_t = (act(c_t) - hw) r + hw -> HBM
 // each with half of the packed FMAs (10 instead of 20 per step) and half of the transcendentals.
 // The hand-over is one pixel (20 steps) deep: the state wave writes pixel s into LDS buffer s & 1 while
@@ -218,6 +220,11 @@ mix_sru_fwd_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
 // then receives whole workgroups whose four waves go to its four SIMDs, one each.  With 2-wave
 // workgroups (two per CU) the second workgroup's waves often landed on the SIMDs the first one already
 // occupied: 0.655 ms instead of 0.396 ms at B = 32 (tools/mix_sru_bench.py).
+//
+// Measured and rejected (round 2): the step's 10 filter responses through LDS broadcast reads (state wave
+// publishes the pixel's 200 values, ten ds_read_b128 per group of 4 steps issued one group ahead as uncounted
+// inline asm) instead of v_readlane -> SGPR: 30 % fewer VALU issue slots, same 0.43 ms -- the wave is bound
+// by its dependent chains, not by issue slots; left to hipcc's own placement the reads cost 0.51 ms.
 constexpr int MP_PAIRS = 2;
 template <int ACT>
 __global__ void __launch_bounds__(2 * MP_PAIRS * WAVE)
@@ -227,7 +234,7 @@ mix_sru_pair_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
                     float *__restrict__ h, float *__restrict__ c_last, int B, int S, int d, int shift_on)
 {
     constexpr int KX = 10, LX = 20, LK = KX * LX, PREG = 4;
-    __shared__ float hand_all[MP_PAIRS][2][LX][WAVE];          // act(c_t) of one pixel, double-buffered, per pair
+    __shared__ float hand_all[MP_PAIRS][2][LX][WAVE];          // act_front(c_t) of one pixel, double-buffered, per pair
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int role = wave & 1;                                // 0 = state wave, 1 = output wave
@@ -339,7 +346,7 @@ mix_sru_pair_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
                     cs[i] = cur;
                 }
 #pragma unroll
-                for (int i = 0; i < G; ++i) hb[(t0 + i) * WAVE] = act_fwd<ACT>(cs[i]);
+                for (int i = 0; i < G; ++i) hb[(t0 + i) * WAVE] = act_front<ACT>(cs[i]);   // tanh: 1 + 2^(-2c log2 e)
             });
             DMN_MP_WAIT(0);                                   // this wave stores nothing to global memory
             DMN_MP_BARRIER();                                 // pixel s is in LDS; the partner has left pixel s - 1
@@ -370,9 +377,12 @@ mix_sru_pair_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
                 for (int i = 0; i < G; ++i) r[i] = fast_exp2(__builtin_fmaf(q[i].x, -MS_LOG2E, bg2));
 #pragma unroll
                 for (int i = 0; i < G; ++i) r[i] = fast_rcp(1.0f + r[i]);
+                float ac_t[G];                                             // act(c_t): the partner did the front half
+#pragma unroll
+                for (int i = 0; i < G; ++i) ac_t[i] = act_back<ACT>(av[t0 + i]);
 #pragma unroll
                 for (int i = 0; i < G; ++i) {
-                    const float hv = __builtin_fmaf(av[t0 + i] - q[i].y, r[i], q[i].y);
+                    const float hv = __builtin_fmaf(ac_t[i] - q[i].y, r[i], q[i].y);
                     __builtin_nontemporal_store(hv, hs + (long long)(t0 + i) * hstride);
                 }
             });
