@@ -292,7 +292,10 @@ mix_sru_pair_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
     // A lone wave issues in order, and one step's 10 packed FMAs are ONE dependent chain (the order of
     // the sum over k is part of the bit-identity contract): G independent chains are interleaved so
     // that the chain's latency, not just its issue slots, is covered.  Same for the transcendentals.
-    constexpr int G = 4;
+#ifndef DMN_MP_G
+#define DMN_MP_G 5   // measured at B = 32: G = 2 0.449 ms, 4 0.426, 5 0.412, 10 0.415
+#endif
+    constexpr int G = DMN_MP_G;
     static_assert(LX % G == 0, "steps are processed in groups of G");
     auto gates = [&](auto gc, const f32x2_t ac, const float (&hold)[PREG], f32x2_t (&q)[G]) {
         constexpr int t0 = decltype(gc)::value * G;
