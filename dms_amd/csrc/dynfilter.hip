@@ -107,6 +107,88 @@ dynfilter_fwd_vec(const float *__restrict__ V, const float *__restrict__ F, floa
     }
 }
 
+// ---- forward on the matrix cores (round 2) ----------------------------------------------------------------
+// Same tiling, chunking and (measured: same) bits as dynfilter_fwd_vec; the 4x4 register tile per lane and
+// its LDS reads (two 16-byte reads per 32 packed FMAs: the kernel was LDS-read bound at 33 % of the fp32
+// peak) are replaced by v_mfma_f32_32x32x2_f32: each of the 4 waves owns a 32 x 32 quarter of the 64 x 64
+// tile, a lane feeds one A and one B scalar per MFMA (row / column lane % 32, k parity lane / 32), read
+// from LDS as 16-byte vectors that serve four MFMAs.  fp32 MFMA adds its two products in k order with a
+// rounding after each, i.e. it continues the same fmaf chain as the vector kernel.
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+constexpr int MF_ROW = 12;               // BK / 2 = 8 k-pairs per row + padding (16-byte aligned rows)
+
+template <bool SPLIT>
+__global__ void __launch_bounds__(256)
+dynfilter_fwd_mfma(const float *__restrict__ V, const float *__restrict__ F, float *__restrict__ P,
+                   int B, int R, int K, int C, int S, int spc, int nch)
+{
+    __shared__ __attribute__((aligned(16))) float As2[2][BM][MF_ROW];   // [k parity][row][k / 2]
+    __shared__ __attribute__((aligned(16))) float Bs2[2][BN][MF_ROW];   // [k parity][col][k / 2]
+    const int b = SPLIT ? (int)blockIdx.z / nch : (int)blockIdx.z, ch = SPLIT ? (int)blockIdx.z % nch : 0;
+    const int r0 = blockIdx.y * BM, s0 = blockIdx.x * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;      // this wave's quarter of the tile
+    const int l32 = lane & 31, half = lane >> 5;
+    const float *Vb = V + (long long)b * C * S;
+    const int steps = (C + BK - 1) / BK;
+    const int st_lo = SPLIT ? ch * spc : 0, st_hi = SPLIT ? min(steps, (ch + 1) * spc) : steps;
+
+    const int ar = tid >> 2, ac = (tid & 3) * 4;     // A: row ar, k-offset ac..ac+3
+    const int bk = tid >> 4, bc = (tid & 15) * 4;    // B: k-row bk, col bc..bc+3
+    const bool a_ok = (r0 + ar) < R;
+    const float *Ap = F + (a_ok ? lbk_row(r0 + ar, b, B, K, C) : 0);
+    const bool b_ok = (s0 + bc) < S;
+
+    f32x16_t acc, tot;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc[i] = 0.0f; tot[i] = 0.0f; }
+    float4 av = make_float4(0, 0, 0, 0), bv = make_float4(0, 0, 0, 0);
+    auto fetch = [&](int c0) {
+        av = (a_ok && c0 + ac < C) ? *reinterpret_cast<const float4 *>(Ap + c0 + ac) : make_float4(0, 0, 0, 0);
+        bv = (b_ok && c0 + bk < C) ? *reinterpret_cast<const float4 *>(Vb + (long long)(c0 + bk) * S + s0 + bc)
+                                   : make_float4(0, 0, 0, 0);
+    };
+    if (st_lo < st_hi) fetch(st_lo * BK);
+    int left = spc;
+    for (int st = st_lo; st < st_hi; ++st) {
+        *reinterpret_cast<float2 *>(&As2[0][ar][ac / 2]) = make_float2(av.x, av.z);
+        *reinterpret_cast<float2 *>(&As2[1][ar][ac / 2]) = make_float2(av.y, av.w);
+        Bs2[bk & 1][bc + 0][bk >> 1] = bv.x; Bs2[bk & 1][bc + 1][bk >> 1] = bv.y;
+        Bs2[bk & 1][bc + 2][bk >> 1] = bv.z; Bs2[bk & 1][bc + 3][bk >> 1] = bv.w;
+        __syncthreads();
+        if (st + 1 < st_hi) fetch((st + 1) * BK);
+        const float4 a0 = *reinterpret_cast<const float4 *>(&As2[half][wm + l32][0]);
+        const float4 a1 = *reinterpret_cast<const float4 *>(&As2[half][wm + l32][4]);
+        const float4 b0 = *reinterpret_cast<const float4 *>(&Bs2[half][wn + l32][0]);
+        const float4 b1 = *reinterpret_cast<const float4 *>(&Bs2[half][wn + l32][4]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, acc, 0, 0, 0);
+        __syncthreads();
+        if (!SPLIT && (--left == 0 || st + 1 == st_hi)) {       // chunk boundary: fold the chunk sum in
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { tot[i] += acc[i]; acc[i] = 0.0f; }
+            left = spc;
+        }
+    }
+    // D layout of 32x32x2: register i of lane (n = lane % 32, h = lane / 32) is row 8 * (i / 4) + 4 * h + i % 4
+    const int sc = s0 + wn + l32;
+    if (sc < S) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = r0 + wm + 8 * (i / 4) + 4 * half + (i % 4);
+            if (r >= R) continue;
+            if (SPLIT) P[(((long long)ch * B + b) * R + r) * S + sc] = acc[i];
+            else P[lbk_row(r, b, B, K, S) + sc] = tot[i];
+        }
+    }
+}
+
 // P[t,b,k,s] = sum over chunks (in chunk order, starting from +0) of ws[chunk][b][r][s]
 __global__ void __launch_bounds__(256)
 dynfilter_reduce(const float *__restrict__ ws, float *__restrict__ P, int B, int R, int K, int S, int nch)
@@ -332,13 +414,17 @@ static int dynfilter_fwd_impl(const char *fn, const float *V, const float *F, fl
     const long long tiles = (long long)grid.x * grid.y * B;
     bool split = workspace && nch > 1 && !((uintptr_t)workspace & 15) && (long long)B * nch <= 65535 &&
                  (se ? atoi(se) != 0 : tiles < 4 * NUM_CU);
+    const char *me = getenv("DMN_DYNFILTER_MFMA");              // 0: the packed-FMA kernels (A/B runs)
+    const bool mfma = !(me && atoi(me) == 0);
     if (split) {
         dim3 sgrid(grid.x, grid.y, B * nch);
-        hipLaunchKernelGGL(dynfilter_fwd_vec<true>, sgrid, dim3(256), 0, s, V, F, workspace, B, R, K, C, S, spc, nch);
+        if (mfma) hipLaunchKernelGGL(dynfilter_fwd_mfma<true>, sgrid, dim3(256), 0, s, V, F, workspace, B, R, K, C, S, spc, nch);
+        else hipLaunchKernelGGL(dynfilter_fwd_vec<true>, sgrid, dim3(256), 0, s, V, F, workspace, B, R, K, C, S, spc, nch);
         const long long n4 = (long long)B * R * S / 4;
         hipLaunchKernelGGL(dynfilter_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, workspace, P, B, R, K, S, nch);
     } else {
-        hipLaunchKernelGGL(dynfilter_fwd_vec<false>, grid, dim3(256), 0, s, V, F, P, B, R, K, C, S, spc, nch);
+        if (mfma) hipLaunchKernelGGL(dynfilter_fwd_mfma<false>, grid, dim3(256), 0, s, V, F, P, B, R, K, C, S, spc, nch);
+        else hipLaunchKernelGGL(dynfilter_fwd_vec<false>, grid, dim3(256), 0, s, V, F, P, B, R, K, C, S, spc, nch);
     }
     return launch_status(fn);
 }

@@ -317,14 +317,22 @@ def test_dynfilter_split_contraction_is_bit_identical_to_the_whole_tile_kernel(B
     V = det_uniform((B, C, S), 96, 1.0).to(DEV)
     Fi = torch.sigmoid(det_uniform((L, B, K, C), 97, 2.0)).to(DEV)
     ref = torch.einsum("tbkc,bcs->tbks", Fi.double().cpu(), V.double().cpu())
-    monkeypatch.setenv("DMN_DYNFILTER_SPLIT", "1")
-    split = ops.dynfilter(V, Fi)
-    monkeypatch.setenv("DMN_DYNFILTER_SPLIT", "0")
-    whole = ops.dynfilter(V, Fi)
-    monkeypatch.delenv("DMN_DYNFILTER_SPLIT")
-    auto = ops.dynfilter(V, Fi)
-    assert torch.equal(split, whole) and torch.equal(auto, whole)
-    assert rel_err(whole.cpu(), ref) < 1e-5
+    res = {}
+    for mfma in ("1", "0"):                                   # matrix-core kernel / packed-FMA kernel
+        monkeypatch.setenv("DMN_DYNFILTER_MFMA", mfma)
+        monkeypatch.setenv("DMN_DYNFILTER_SPLIT", "1")
+        split = ops.dynfilter(V, Fi)
+        monkeypatch.setenv("DMN_DYNFILTER_SPLIT", "0")
+        whole = ops.dynfilter(V, Fi)
+        monkeypatch.delenv("DMN_DYNFILTER_SPLIT")
+        auto = ops.dynfilter(V, Fi)
+        assert torch.equal(split, whole) and torch.equal(auto, whole), mfma
+        assert rel_err(whole.cpu(), ref) < 1e-5, mfma
+        res[mfma] = whole
+    monkeypatch.delenv("DMN_DYNFILTER_MFMA")
+    # fp32 MFMA continues the same k-ordered fmaf chain: the two kernels agree bit for bit
+    assert torch.equal(res["1"], res["0"])
+    whole = res["1"]
     # a sample alone == the same sample inside the batch, bit for bit
     if B > 1:
         alone = ops.dynfilter(V[1:2].contiguous(), Fi[:, 1:2].contiguous())

@@ -12,8 +12,9 @@ for B in (1, 2, 4, 8, 16, 32, 64):
     V = torch.randn((B, C, S), device=dev, generator=g)
     F = torch.rand((L, B, K, C), device=dev, generator=g)
     res = []
-    for mode in ("0", "1"):
-        os.environ["DMN_DYNFILTER_SPLIT"] = mode
+    for mode in ("0", "1", "0m", "1m"):
+        os.environ["DMN_DYNFILTER_SPLIT"] = mode[0]
+        os.environ["DMN_DYNFILTER_MFMA"] = "1" if mode.endswith("m") else "0"
         for _ in range(3):
             ops.dynfilter(V, F)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -23,8 +24,8 @@ for B in (1, 2, 4, 8, 16, 32, 64):
         b.record(); torch.cuda.synchronize()
         res.append(a.elapsed_time(b) / 20)
     fl = 2.0 * B * L * K * C * S
-    print("B=%2d: whole tiles %.4f ms (%.1f TFLOP/s)   split %.4f ms (%.1f TFLOP/s)" % (
-        B, res[0], fl / res[0] / 1e9, res[1], fl / res[1] / 1e9), flush=True)
+    print("B=%2d: packed FMA whole %.4f ms (%.1f TF) split %.4f ms (%.1f TF) | MFMA whole %.4f ms (%.1f TF) split %.4f ms (%.1f TF)" % (
+        B, res[0], fl / res[0] / 1e9, res[1], fl / res[1] / 1e9, res[2], fl / res[2] / 1e9, res[3], fl / res[3] / 1e9), flush=True)
 
 # backward at the training shape (configs[3]: 320 px low-res, S = 100, B = 64)
 from dms_amd import _lib
