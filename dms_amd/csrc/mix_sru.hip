@@ -397,6 +397,182 @@ mix_sru_pair_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
 #undef DMN_MP_BARRIER
 }
 
+// ------------------------------------------------------------------------------------------------
+// K = 10, L = 20, S % 8 == 0: the rank-10 update on the matrix cores (round 2).
+//
+// In the pair kernel above the 40 FMAs of a step and the 2 x 10 v_readlane that feed them are 60 % of the
+// VALU issue slots, and at B = 32 every SIMD already holds a wave: only another pipe can take work away.
+// For a block of 32 consecutive steps the pre-activations of one gate of 32 columns are a 32 x 32 tile
+//     D[t, c] = (A[s(t), c] + Bt[l(t), c])  +  sum_k P[t, k] * Wp[c, k]
+// i.e. five v_mfma_f32_32x32x2_f32 (k = 0..9 in pairs) on top of an accumulator initialised with A + Bt.
+// fp32 MFMA adds its two products in k order with a rounding after each (measured: the dynamic-filter
+// kernels agree bit for bit), so this continues the SAME fmaf chain as dmn_mix_bcast_add and h stays
+// bit-identical to dmn_mix_bcast_add + dmn_sru_fwd.
+//
+// Roles as in the pair kernel (state wave: u0, forget -> c_t, front half of the activation -> LDS; output
+// wave: reset, highway -> h), one block of 32 steps apart, one s_barrier per block.  A wave owns 64 columns
+// as two sets X (lanes' columns 0..31 of the window) and Y (32..63) x its 2 gates = four accumulators.
+// The MFMA result layout gives lane (n, hf = lane / 32) rows 8 (r / 4) + 4 hf + r % 4 of column n in register
+// r: half of the time steps of a column sit in the other half-wave.  One v_permlane32_swap per register
+// pair (X_r, Y_r) fixes that: afterwards lane n < 32 owns column X_n, lane n >= 32 column Y_(n-32) -- the
+// window's natural column order -- with steps 8 q .. 8 q + 3 in X_(4q ..) and 8 q + 4 .. 8 q + 7 in Y_(4q ..).
+// Time is walked in super-blocks of 160 steps (8 pixels = 5 blocks) so that a block's pixel / word of every
+// accumulator register is a compile-time constant; the half-wave's +4 step offset is folded into a
+// per-lane rotated copy of the column's Bt rows.
+typedef float f32x16m_t __attribute__((ext_vector_type(16)));
+template <int ACT>
+__global__ void __launch_bounds__(2 * MP_PAIRS * WAVE)
+mix_sru_mfma_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
+                    const float *__restrict__ Pt, const float *__restrict__ Wp, int ldw,
+                    const float *__restrict__ bias, const float *__restrict__ c0,
+                    float *__restrict__ h, float *__restrict__ c_last, int B, int S, int d, int shift_on)
+{
+    constexpr int KX = 10, LX = 20, BLK = 32, NBLK = 5, PIX = 8;
+    __shared__ float hand_all[MP_PAIRS][2][BLK][WAVE];        // act_front(c_t) of one block, double-buffered, per pair
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int role = wave & 1;                                // 0 = state wave, 1 = output wave
+    float (*hand)[BLK][WAVE] = hand_all[wave >> 1];
+    const int win = (int)blockIdx.x * MP_PAIRS + (wave >> 1);
+    const int b = blockIdx.y;
+    const int sh = shift_on ? (int)(((long long)b * d) & 15) : 0;
+    const int n32 = lane & 31, hf = lane >> 5;
+    auto clampj = [&](int jr) { return jr < 0 ? 0 : (jr < d ? jr : d - 1); };
+    const int jset[2] = {clampj(win * WAVE + n32 - sh), clampj(win * WAVE + 32 + n32 - sh)};   // X / Y column of lane n32
+    const int jraw = win * WAVE + lane - sh;
+    const int j = clampj(jraw);                               // the column this lane owns after the swap
+    const int M4 = 4 * d;
+    const int col = b * d + j;
+    const int g0 = 2 * role;
+
+    // B operands: Wp[c, 2 jj + hf] of the lane's X / Y column, both gates
+    float wB[2][2][KX / 2];
+    float bth[2][2][LX];                                      // Bt row (l + 4 hf) % 20: the half-wave's rows are 4 steps later
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {
+            const long long c = 4 * jset[st] + g0 + gg;
+#pragma unroll
+            for (int jj = 0; jj < KX / 2; ++jj) wB[st][gg][jj] = Wp[c * ldw + 2 * jj + hf];
+#pragma unroll
+            for (int l = 0; l < LX; ++l) {
+                int lr = l + 4 * hf;
+                lr = lr >= LX ? lr - LX : lr;
+                bth[st][gg][l] = Bt[((long long)lr * B + b) * M4 + c];
+            }
+        }
+    const float bg2 = -MS_LOG2E * bias[j + role * d];
+    const float *Ab = A + (long long)b * S * M4;
+    const float *pb = Pt + (long long)b * S * (KX * LX) + n32 * KX + hf;   // P[t = n32, k = hf] of the sample
+    float cur = (role == 0 && c0) ? c0[col] : 0.0f;
+    float *hp = h + col;
+    const long long hstride = (long long)B * d;
+#define DMN_MM_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+    const int nsup = S / PIX;
+    if (role == 1) DMN_MM_BARRIER();                          // block 0 of the state wave is in LDS
+    int parity = 0;                                           // hand-over buffer of the block being processed
+    for (int sb = 0; sb < nsup; ++sb) {
+        // A of the super-block's 8 pixels: the lane's X / Y column, both gates
+        float av[2][2][PIX];
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int px = 0; px < PIX; ++px) {
+                const float2 v = *reinterpret_cast<const float2 *>(Ab + (long long)(sb * PIX + px) * M4 + 4 * jset[st] + g0);
+                av[st][0][px] = v.x;
+                av[st][1][px] = v.y;
+            }
+        static_for_t<0, NBLK>([&](auto bc) {
+            constexpr int blk = decltype(bc)::value;
+            const long long T0 = (long long)sb * (PIX * LX) + blk * BLK;       // first step of the block
+            float pa[KX / 2];
+#pragma unroll
+            for (int jj = 0; jj < KX / 2; ++jj) pa[jj] = pb[T0 * KX + 2 * jj];
+            f32x16m_t acc[2][2];
+            static_for_t<0, 16>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                constexpr int t0r = blk * BLK + 8 * (r / 4) + r % 4;          // hf = 0 step of register r (hf = 1: + 4)
+                constexpr int l0 = t0r % LX, p0 = t0r / LX, p1 = (t0r + 4) / LX;
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int gg = 0; gg < 2; ++gg) {
+                        const float a = (p0 == p1) ? av[st][gg][p0] : (hf ? av[st][gg][p1 < PIX ? p1 : p0] : av[st][gg][p0]);
+                        acc[st][gg][r] = a + bth[st][gg][l0];
+                    }
+            });
+#pragma unroll
+            for (int jj = 0; jj < KX / 2; ++jj)
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int gg = 0; gg < 2; ++gg)
+                        acc[st][gg] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[jj], wB[st][gg][jj], acc[st][gg], 0, 0, 0);
+            // half-wave exchange: lanes < 32 keep column X, lanes >= 32 take column Y
+            float q[2][BLK];                                  // [gate][step of the block]
+            static_for_t<0, 16>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                constexpr int i0 = 8 * (r / 4) + r % 4;
+#pragma unroll
+                for (int gg = 0; gg < 2; ++gg) {
+                    // (element -> float temporaries first: __builtin_bit_cast applied to a vector-element
+                    //  lvalue reads element 0 whatever the index with this compiler)
+                    const float xr = acc[0][gg][r], yr = acc[1][gg][r];
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(xr), __float_as_uint(yr), false, false);
+                    const unsigned s0 = sw[0], s1 = sw[1];
+                    q[gg][i0] = __uint_as_float(s0);
+                    q[gg][i0 + 4] = __uint_as_float(s1);
+                }
+            });
+            if (role == 0) {
+                float *hb = &hand[parity][0][lane];
+                static_for_t<0, BLK / 4>([&](auto gc) {
+                    constexpr int i0 = decltype(gc)::value * 4;
+                    float f[4], cs[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) f[i] = fast_exp2(__builtin_fmaf(q[1][i0 + i], -MS_LOG2E, bg2));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) f[i] = fast_rcp(1.0f + f[i]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        cur = __builtin_fmaf(cur - q[0][i0 + i], f[i], q[0][i0 + i]);
+                        cs[i] = cur;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) hb[(i0 + i) * WAVE] = act_front<ACT>(cs[i]);
+                });
+            } else {
+                const float *hb = &hand[parity][0][lane];
+                float *hs = hp + T0 * hstride;
+                static_for_t<0, BLK / 4>([&](auto gc) {
+                    constexpr int i0 = decltype(gc)::value * 4;
+                    float r[4], ac_t[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) r[i] = fast_exp2(__builtin_fmaf(q[0][i0 + i], -MS_LOG2E, bg2));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) r[i] = fast_rcp(1.0f + r[i]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) ac_t[i] = act_back<ACT>(hb[(i0 + i) * WAVE]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float hv = __builtin_fmaf(ac_t[i] - q[1][i0 + i], r[i], q[1][i0 + i]);
+                        __builtin_nontemporal_store(hv, hs + (long long)(i0 + i) * hstride);
+                    }
+                });
+            }
+            parity ^= 1;
+            DMN_MM_BARRIER();
+        });
+    }
+    if (role == 0) {
+        DMN_MM_BARRIER();                                     // pairs with the partner's last block
+        if (c_last && jraw == j) c_last[col] = cur;
+    }
+#undef DMN_MM_BARRIER
+}
+
 }  // namespace dmn
 
 using namespace dmn;
@@ -423,6 +599,21 @@ extern "C" int dmn_mix_sru_fwd(const float *A, const float *Bt, const float *Pt,
         const int shift_on = ((long long)B * d) % 16 == 0 && (d + 15 + WAVE - 1) / WAVE == (d + WAVE - 1) / WAVE;
         const int nwin = (d + (shift_on ? 15 : 0) + WAVE - 1) / WAVE;
         dim3 pgrid((nwin + MP_PAIRS - 1) / MP_PAIRS, B);
+        // whole 8-pixel super-blocks: the rank-10 update on the matrix cores (DMN_MIX_SRU_MFMA=0: VALU pair
+        // kernel, =1: always).  Its 272 VGPRs allow one wave per SIMD, so by itself it is taken only while the
+        // grid fits the chip in one round (measured at S = 256: 0.381 vs 0.412 ms at B = 32, but 0.804 vs 0.770
+        // at B = 64, where the pair kernel's waves share the SIMDs).
+        const char *me = getenv("DMN_MIX_SRU_MFMA");
+        const bool one_round = (long long)pgrid.x * pgrid.y * 2 * MP_PAIRS <= 4LL * NUM_CU;
+        if (S % 8 == 0 && !(((uintptr_t)A) & 7) && (me ? atoi(me) != 0 : one_round)) {
+#define DMN_MM(ACTV) hipLaunchKernelGGL((mix_sru_mfma_kernel<ACTV>), pgrid, dim3(2 * MP_PAIRS * WAVE), 0, s, A, Bt, Pt, Wp, ldw, \
+                                        bias, c0, h, c_last, B, S, d, shift_on)
+            if (act == DMN_ACT_TANH) DMN_MM(DMN_ACT_TANH);
+            else if (act == DMN_ACT_RELU) DMN_MM(DMN_ACT_RELU);
+            else DMN_MM(DMN_ACT_IDENTITY);
+#undef DMN_MM
+            return launch_status("dmn_mix_sru_fwd");
+        }
 #define DMN_MP(ACTV) hipLaunchKernelGGL((mix_sru_pair_kernel<ACTV>), pgrid, dim3(2 * MP_PAIRS * WAVE), 0, s, A, Bt, Pt, Wp, ldw, \
                                         bias, c0, h, c_last, B, S, d, shift_on)
         if (act == DMN_ACT_TANH) DMN_MP(DMN_ACT_TANH);

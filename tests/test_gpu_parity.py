@@ -477,7 +477,11 @@ def test_hot_path_matches_reference_golden(name):
                                        (1, 3, 16, 5, 130), (2, 1, 10, 1, 5), (1, 20, 10, 3, 70), (3, 20, 10, 1, 64),
                                        # K = 10, L = 20 with B*d a multiple of 16: the two-wave kernel with its
                                        # 64-byte-aligned (shifted) column windows, incl. windows that start below column 0
-                                       (16, 20, 10, 3, 1005), (32, 20, 10, 2, 1005), (2, 20, 10, 4, 1000), (4, 20, 10, 2, 100)])
+                                       (16, 20, 10, 3, 1005), (32, 20, 10, 2, 1005), (2, 20, 10, 4, 1000), (4, 20, 10, 2, 100),
+                                       # ... and with S a multiple of 8: the matrix-core kernel (blocks of 32 steps,
+                                       # super-blocks of 8 pixels), one and several super-blocks, ragged last window
+                                       (2, 20, 10, 8, 64), (1, 20, 10, 16, 1005), (3, 20, 10, 24, 1000), (16, 20, 10, 8, 1005),
+                                       (5, 20, 10, 8, 70)])
 @pytest.mark.parametrize("act", ACTS)
 def test_mix_fused_into_layer0_scan_is_bit_identical_to_mix_then_scan(B, L, K, S, d, act):
     """dmn_mix_sru_fwd == dmn_sru_fwd(dmn_mix_bcast_add(...)) bit for bit (h and c_last), with and
@@ -495,6 +499,14 @@ def test_mix_fused_into_layer0_scan_is_bit_identical_to_mix_then_scan(B, L, K, S
         h_ref, _, c_ref = ops.sru_forward_raw(U0, None, bias, init, act, 1.0, nchunks=1)
         h, c = ops.mix_sru_fwd(A, Bt, P, Wp, bias, init, act)
         assert h.shape == (S * L, B, d) and torch.equal(h, h_ref) and torch.equal(c, c_ref)
+        if K == 10 and L == 20 and S % 8 == 0:                 # both two-wave kernels, whatever the library picks
+            for force in ("0", "1"):
+                os.environ["DMN_MIX_SRU_MFMA"] = force
+                try:
+                    hv, cv = ops.mix_sru_fwd(A, Bt, P, Wp, bias, init, act)
+                finally:
+                    del os.environ["DMN_MIX_SRU_MFMA"]
+                assert torch.equal(hv, h_ref) and torch.equal(cv, c_ref), "DMN_MIX_SRU_MFMA=" + force
     want = (A.permute(1, 0, 2)[:, None] + Bt[None] + torch.einsum("mk,tbks->stbm", Wp, P)).reshape(S * L, B, d, 4)
     h_o, _, c_o = sru_ref.sru_fwd_c(want.cpu().numpy(), None, bias.cpu().numpy(), c0.cpu().numpy(), act, 1.0)
     np.testing.assert_allclose(h.cpu().numpy(), h_o, rtol=1e-4, atol=1e-5)

@@ -38,8 +38,16 @@ for B in (2, 4, 8, 12, 16, 32, 64):
     os.environ["DMN_MIX_SRU_PAIR"] = "0"
     t_single = timeit(lambda: ops.mix_sru_fwd(A, Bt, P, W, bias, None, "tanh"))
     os.environ["DMN_MIX_SRU_PAIR"] = "1"
+    os.environ["DMN_MIX_SRU_MFMA"] = "0"
     t_two = timeit(lambda: ops.mix_sru_fwd(A, Bt, P, W, bias, None, "tanh"))
-    same = torch.equal(ops.mix_sru_fwd(A, Bt, P, W, bias, None, "tanh")[0], pair()[0])
-    print("B=%2d: mix + scan %.3f ms   fused single-wave %.3f ms   fused two-wave %.3f ms   bit-identical %s"
-          % (B, t_pair, t_single, t_two, same), flush=True)
+    h_two = ops.mix_sru_fwd(A, Bt, P, W, bias, None, "tanh")[0]
+    os.environ["DMN_MIX_SRU_MFMA"] = "1"
+    t_mfma = timeit(lambda: ops.mix_sru_fwd(A, Bt, P, W, bias, None, "tanh"))
+    h_mfma = ops.mix_sru_fwd(A, Bt, P, W, bias, None, "tanh")[0]
+    del os.environ["DMN_MIX_SRU_MFMA"]
+    t_auto = timeit(lambda: ops.mix_sru_fwd(A, Bt, P, W, bias, None, "tanh"))
+    same = torch.equal(h_two, pair()[0])
+    print("B=%2d: mix + scan %.3f ms   fused single-wave %.3f   two-wave VALU %.3f   two-wave MFMA %.3f   by itself %.3f ms   "
+          "VALU == mix + scan %s   MFMA == VALU %s"
+          % (B, t_pair, t_single, t_two, t_mfma, t_auto, same, torch.equal(h_mfma, h_two)), flush=True)
     del A, Bt, P, W
