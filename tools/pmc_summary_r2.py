@@ -35,13 +35,14 @@ LABELS = {
     ("dmn::sru_fwd_cols<4, 1, 8, true>", 64320): ("sru_fwd k=4 T=2000 cols=64320", 24 * EB),
     ("dmn::sru_bwd_cols<3, 1, 4>", 64320): ("sru_bwd k=3 T=2000 cols=64320", 40 * EB),
     ("dmn::sru_bwd_cols<4, 1, 4>", 64320): ("sru_bwd k=4 T=2000 cols=64320", 40 * EB),
-    ("dmn::mix_sru_pair_kernel<1>", 65536): ("mix+sru_fwd fused k=4 T=5120 cols=32160 (issue-bound)", 807208960),
+    ("dmn::mix_sru_pair_kernel<1>", 65536): ("mix+sru_fwd fused k=4 T=5120 cols=32160 (issue-bound), VALU pair kernel", 807208960),
+    ("dmn::mix_sru_mfma_kernel<1>", 65536): ("mix+sru_fwd fused k=4 T=5120 cols=32160 (issue-bound)", 807208960),
 }
 out = {"_how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/profile_round2.sh over "
                "tools/pmc_round2.py and tools/pmc_scan.py; tools/profile_tap_r2.sh for the tap_gather levels after their final store / load policy). "
                "Units KiB, median of the launches; hbm_bytes = 2 x FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE reports "
                "half of a wide streaming read; WRITE_SIZE exact).  The fused mix+scan kernel re-reads small L2-resident "
-               "operands (Bt, P, Wp) that the x2 rule over-counts: its WRITE_SIZE alone is +0.7 % over the h bytes (round 1: +11 %)."}
+               "operands (Bt, P, Wp) that the x2 rule over-counts: its WRITE_SIZE alone is +2.2 % over the h bytes (VALU pair kernel +0.7 %, round 1 single-wave kernel +11 %)."}
 for key, (label, alg) in LABELS.items():
     if key in fetch and key in write:
         hb = int(round((2 * fetch[key] + write[key]) * 1024))

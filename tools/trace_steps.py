@@ -33,7 +33,7 @@ for name, (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:topn]:
 # launches of the LONGEST class (within 2x of the longest) separately: that is the launch
 # bench.py's `roofline` object times with HIP events.
 for name, d in sorted(durs.items()):
-    if "sru_fwd_cols" in name or "mix_sru_fwd" in name:
+    if "sru_fwd_cols" in name or "mix_sru" in name:
         top = max(d)
         big = [x for x in d if x > top / 2]
         print("longest class of %s: %d launches, avg %.1f us (min %.1f, max %.1f)"
