@@ -417,11 +417,11 @@ mix_sru_pair_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
 // pair (X_r, Y_r) fixes that: afterwards lane n < 32 owns column X_n, lane n >= 32 column Y_(n-32) -- the
 // window's natural column order -- with steps 8 q .. 8 q + 3 in X_(4q ..) and 8 q + 4 .. 8 q + 7 in Y_(4q ..).
 // Time is walked in super-blocks of 160 steps (8 pixels = 5 blocks) so that a block's pixel / word of every
-// accumulator register is a compile-time constant; the half-wave's +4 step offset is folded into a
-// per-lane rotated copy of the column's Bt rows.
+// accumulator register is a compile-time constant; the half-wave's +4 step offset becomes a per-lane
+// rotation of the word-group index under which the column's Bt rows are read from LDS.
 typedef float f32x16m_t __attribute__((ext_vector_type(16)));
 template <int ACT>
-__global__ void __launch_bounds__(2 * MP_PAIRS * WAVE)
+__global__ void __launch_bounds__(2 * MP_PAIRS * WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)))
 mix_sru_mfma_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
                     const float *__restrict__ Pt, const float *__restrict__ Wp, int ldw,
                     const float *__restrict__ bias, const float *__restrict__ c0,
@@ -429,6 +429,10 @@ mix_sru_mfma_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
 {
     constexpr int KX = 10, LX = 20, BLK = 32, NBLK = 5, PIX = 8;
     __shared__ float hand_all[MP_PAIRS][2][BLK][WAVE];        // act_front(c_t) of one block, double-buffered, per pair
+    // The wave's Bt rows (64 columns x 2 gates x 20 words) live in LDS, four words to a 16-byte entry, instead
+    // of 80 registers per lane: with them in registers the kernel needs 272 VGPRs, hipcc parks the MFMA tiles
+    // in AGPRs and every block pays 128 v_accvgpr moves.  Under 256 (waves_per_eu above) the tiles stay in VGPRs.
+    __shared__ float4 bt_all[2 * MP_PAIRS][2][LX / 4][WAVE];  // [wave][gate][word group][window column]
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int role = wave & 1;                                // 0 = state wave, 1 = output wave
@@ -447,7 +451,6 @@ mix_sru_mfma_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
 
     // B operands: Wp[c, 2 jj + hf] of the lane's X / Y column, both gates
     float wB[2][2][KX / 2];
-    float bth[2][2][LX];                                      // Bt row (l + 4 hf) % 20: the half-wave's rows are 4 steps later
 #pragma unroll
     for (int st = 0; st < 2; ++st)
 #pragma unroll
@@ -455,13 +458,23 @@ mix_sru_mfma_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
             const long long c = 4 * jset[st] + g0 + gg;
 #pragma unroll
             for (int jj = 0; jj < KX / 2; ++jj) wB[st][gg][jj] = Wp[c * ldw + 2 * jj + hf];
-#pragma unroll
-            for (int l = 0; l < LX; ++l) {
-                int lr = l + 4 * hf;
-                lr = lr >= LX ? lr - LX : lr;
-                bth[st][gg][l] = Bt[((long long)lr * B + b) * M4 + c];
-            }
         }
+    // lane l stages window column l (its own column j); read back per set as column st * 32 + n32.  The
+    // half-wave hf = 1 holds the tile rows 4 steps later = the NEXT word group (20 words: groups wrap mod 5).
+    float4 (*btw)[LX / 4][WAVE] = bt_all[wave];
+#pragma unroll
+    for (int grp = 0; grp < LX / 4; ++grp) {
+        float2 v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            v[e] = *reinterpret_cast<const float2 *>(Bt + ((long long)(4 * grp + e) * B + b) * M4 + 4 * j + g0);
+        btw[0][grp][lane] = make_float4(v[0].x, v[1].x, v[2].x, v[3].x);
+        btw[1][grp][lane] = make_float4(v[0].y, v[1].y, v[2].y, v[3].y);
+    }
+    int gsel[LX / 4];                                         // entry of word group g for this half-wave, set X
+#pragma unroll
+    for (int g = 0; g < LX / 4; ++g) gsel[g] = ((g + hf) % (LX / 4)) * WAVE + n32;
+    __syncthreads();
     const float bg2 = -MS_LOG2E * bias[j + role * d];
     const float *Ab = A + (long long)b * S * M4;
     const float *pb = Pt + (long long)b * S * (KX * LX) + n32 * KX + hf;   // P[t = n32, k = hf] of the sample
@@ -491,16 +504,23 @@ mix_sru_mfma_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
 #pragma unroll
             for (int jj = 0; jj < KX / 2; ++jj) pa[jj] = pb[T0 * KX + 2 * jj];
             f32x16m_t acc[2][2];
-            static_for_t<0, 16>([&](auto rc) {
-                constexpr int r = decltype(rc)::value;
-                constexpr int t0r = blk * BLK + 8 * (r / 4) + r % 4;          // hf = 0 step of register r (hf = 1: + 4)
-                constexpr int l0 = t0r % LX, p0 = t0r / LX, p1 = (t0r + 4) / LX;
+            static_for_t<0, 4>([&](auto qc) {
+                constexpr int q4 = decltype(qc)::value;
+                constexpr int tq = blk * BLK + 8 * q4;                          // hf = 0 step of register 4 q4 (hf = 1: + 4)
+                constexpr int G0 = (tq % LX) / 4;                               // its word group (a multiple of 4 steps in)
+                const float4 *bsrc = &btw[0][0][0] + gsel[G0];
 #pragma unroll
                 for (int st = 0; st < 2; ++st)
 #pragma unroll
                     for (int gg = 0; gg < 2; ++gg) {
-                        const float a = (p0 == p1) ? av[st][gg][p0] : (hf ? av[st][gg][p1 < PIX ? p1 : p0] : av[st][gg][p0]);
-                        acc[st][gg][r] = a + bth[st][gg][l0];
+                        const float4 bt4 = bsrc[gg * (LX / 4) * WAVE + st * 32];
+                        const float bte[4] = {bt4.x, bt4.y, bt4.z, bt4.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int t0r = tq + e, p0 = t0r / LX, p1 = (t0r + 4) / LX;   // p1 <= 7: 159 is the last step
+                            const float a = (p0 == p1 || !hf) ? av[st][gg][p0] : av[st][gg][p1];
+                            acc[st][gg][4 * q4 + e] = a + bte[e];
+                        }
                     }
             });
 #pragma unroll
@@ -599,13 +619,11 @@ extern "C" int dmn_mix_sru_fwd(const float *A, const float *Bt, const float *Pt,
         const int shift_on = ((long long)B * d) % 16 == 0 && (d + 15 + WAVE - 1) / WAVE == (d + WAVE - 1) / WAVE;
         const int nwin = (d + (shift_on ? 15 : 0) + WAVE - 1) / WAVE;
         dim3 pgrid((nwin + MP_PAIRS - 1) / MP_PAIRS, B);
-        // whole 8-pixel super-blocks: the rank-10 update on the matrix cores (DMN_MIX_SRU_MFMA=0: VALU pair
-        // kernel, =1: always).  Its 272 VGPRs allow one wave per SIMD, so by itself it is taken only while the
-        // grid fits the chip in one round (measured at S = 256: 0.381 vs 0.412 ms at B = 32, but 0.804 vs 0.770
-        // at B = 64, where the pair kernel's waves share the SIMDs).
+        // whole 8-pixel super-blocks: the rank-10 update on the matrix cores (DMN_MIX_SRU_MFMA=0: the VALU pair
+        // kernel).  147 VGPRs and 72 KB of LDS: two workgroups share a CU from B = 64 on (measured at S = 256:
+        // 0.354 vs 0.411 ms at B = 32, 0.630 vs 0.760 at B = 64).
         const char *me = getenv("DMN_MIX_SRU_MFMA");
-        const bool one_round = (long long)pgrid.x * pgrid.y * 2 * MP_PAIRS <= 4LL * NUM_CU;
-        if (S % 8 == 0 && !(((uintptr_t)A) & 7) && (me ? atoi(me) != 0 : one_round)) {
+        if (S % 8 == 0 && !(((uintptr_t)A | (uintptr_t)Bt) & 7) && !(me && atoi(me) == 0)) {
 #define DMN_MM(ACTV) hipLaunchKernelGGL((mix_sru_mfma_kernel<ACTV>), pgrid, dim3(2 * MP_PAIRS * WAVE), 0, s, A, Bt, Pt, Wp, ldw, \
                                         bias, c0, h, c_last, B, S, d, shift_on)
             if (act == DMN_ACT_TANH) DMN_MM(DMN_ACT_TANH);
