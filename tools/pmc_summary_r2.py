@@ -42,7 +42,7 @@ out = {"_how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate pass
                "tools/pmc_round2.py and tools/pmc_scan.py; tools/profile_tap_r2.sh for the tap_gather levels after their final store / load policy). "
                "Units KiB, median of the launches; hbm_bytes = 2 x FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE reports "
                "half of a wide streaming read; WRITE_SIZE exact).  The fused mix+scan kernel re-reads small L2-resident "
-               "operands (Bt, P, Wp) that the x2 rule over-counts: its WRITE_SIZE alone is +2.2 % over the h bytes (VALU pair kernel +0.7 %, round 1 single-wave kernel +11 %)."}
+               "operands (Bt, P, Wp) that the x2 rule over-counts: its WRITE_SIZE alone is +2.4 % over the h bytes (VALU pair kernel +0.7 %, round 1 single-wave kernel +11 %)."}
 for key, (label, alg) in LABELS.items():
     if key in fetch and key in write:
         hb = int(round((2 * fetch[key] + write[key]) * 1024))
