@@ -398,7 +398,7 @@ mix_sru_pair_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
 }
 
 // ------------------------------------------------------------------------------------------------
-// K = 10, L = 20, S % 8 == 0: the rank-10 update on the matrix cores (round 2).
+// K = 10, L = 20: the rank-10 update on the matrix cores (round 2).
 //
 // In the pair kernel above the 40 FMAs of a step and the 2 x 10 v_readlane that feed them are 60 % of the
 // VALU issue slots, and at B = 32 every SIMD already holds a wave: only another pipe can take work away.
@@ -483,26 +483,43 @@ mix_sru_mfma_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
     const long long hstride = (long long)B * d;
 #define DMN_MM_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-    const int nsup = S / PIX;
+    const long long Ttot = (long long)S * LX;
     if (role == 1) DMN_MM_BARRIER();                          // block 0 of the state wave is in LDS
     int parity = 0;                                           // hand-over buffer of the block being processed
-    for (int sb = 0; sb < nsup; ++sb) {
+    // One super-block.  TAIL: the last, partial one when S is not a multiple of 8 -- its own copy of the code,
+    // run once: pixels / P rows past the end are clamped (their tile rows are never read out), blocks and
+    // 4-step groups past the end are skipped by both roles alike (20 steps per pixel: the end is on a group).
+    auto super_block = [&](int sb, auto tailc) {
+        constexpr bool TAIL = decltype(tailc)::value != 0;
+        const int nst = TAIL ? (S - sb * PIX) * LX : PIX * LX;                 // steps of this super-block
         // A of the super-block's 8 pixels: the lane's X / Y column, both gates
         float av[2][2][PIX];
 #pragma unroll
         for (int st = 0; st < 2; ++st)
 #pragma unroll
             for (int px = 0; px < PIX; ++px) {
-                const float2 v = *reinterpret_cast<const float2 *>(Ab + (long long)(sb * PIX + px) * M4 + 4 * jset[st] + g0);
+                int sp = sb * PIX + px;
+                if (TAIL) sp = sp < S ? sp : S - 1;
+                const float2 v = *reinterpret_cast<const float2 *>(Ab + (long long)sp * M4 + 4 * jset[st] + g0);
                 av[st][0][px] = v.x;
                 av[st][1][px] = v.y;
             }
         static_for_t<0, NBLK>([&](auto bc) {
             constexpr int blk = decltype(bc)::value;
+            if constexpr (TAIL) {
+                if (blk * BLK >= nst) return;
+            }
             const long long T0 = (long long)sb * (PIX * LX) + blk * BLK;       // first step of the block
             float pa[KX / 2];
+            if constexpr (TAIL) {
+                const long long tr = T0 + n32 < Ttot ? T0 + n32 : Ttot - 1;
+                const float *pr = Pt + ((long long)b * Ttot + tr) * KX + hf;
 #pragma unroll
-            for (int jj = 0; jj < KX / 2; ++jj) pa[jj] = pb[T0 * KX + 2 * jj];
+                for (int jj = 0; jj < KX / 2; ++jj) pa[jj] = pr[2 * jj];
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < KX / 2; ++jj) pa[jj] = pb[T0 * KX + 2 * jj];
+            }
             f32x16m_t acc[2][2];
             static_for_t<0, 4>([&](auto qc) {
                 constexpr int q4 = decltype(qc)::value;
@@ -550,6 +567,9 @@ mix_sru_mfma_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
                 float *hb = &hand[parity][0][lane];
                 static_for_t<0, BLK / 4>([&](auto gc) {
                     constexpr int i0 = decltype(gc)::value * 4;
+                    if constexpr (TAIL) {
+                        if (blk * BLK + i0 >= nst) return;
+                    }
                     float f[4], cs[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) f[i] = fast_exp2(__builtin_fmaf(q[1][i0 + i], -MS_LOG2E, bg2));
@@ -568,6 +588,9 @@ mix_sru_mfma_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
                 float *hs = hp + T0 * hstride;
                 static_for_t<0, BLK / 4>([&](auto gc) {
                     constexpr int i0 = decltype(gc)::value * 4;
+                    if constexpr (TAIL) {
+                        if (blk * BLK + i0 >= nst) return;
+                    }
                     float r[4], ac_t[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) r[i] = fast_exp2(__builtin_fmaf(q[0][i0 + i], -MS_LOG2E, bg2));
@@ -585,7 +608,9 @@ mix_sru_mfma_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
             parity ^= 1;
             DMN_MM_BARRIER();
         });
-    }
+    };
+    for (int sb = 0; sb < S / PIX; ++sb) super_block(sb, TC<0>{});
+    if (S % PIX) super_block(S / PIX, TC<1>{});
     if (role == 0) {
         DMN_MM_BARRIER();                                     // pairs with the partner's last block
         if (c_last && jraw == j) c_last[col] = cur;
@@ -619,11 +644,11 @@ extern "C" int dmn_mix_sru_fwd(const float *A, const float *Bt, const float *Pt,
         const int shift_on = ((long long)B * d) % 16 == 0 && (d + 15 + WAVE - 1) / WAVE == (d + WAVE - 1) / WAVE;
         const int nwin = (d + (shift_on ? 15 : 0) + WAVE - 1) / WAVE;
         dim3 pgrid((nwin + MP_PAIRS - 1) / MP_PAIRS, B);
-        // whole 8-pixel super-blocks: the rank-10 update on the matrix cores (DMN_MIX_SRU_MFMA=0: the VALU pair
+        // the rank-10 update on the matrix cores (DMN_MIX_SRU_MFMA=0: the VALU pair
         // kernel).  147 VGPRs and 72 KB of LDS: two workgroups share a CU from B = 64 on (measured at S = 256:
         // 0.354 vs 0.411 ms at B = 32, 0.630 vs 0.760 at B = 64).
         const char *me = getenv("DMN_MIX_SRU_MFMA");
-        if (S % 8 == 0 && !(((uintptr_t)A | (uintptr_t)Bt) & 7) && !(me && atoi(me) == 0)) {
+        if (!(((uintptr_t)A | (uintptr_t)Bt) & 7) && !(me && atoi(me) == 0)) {
 #define DMN_MM(ACTV) hipLaunchKernelGGL((mix_sru_mfma_kernel<ACTV>), pgrid, dim3(2 * MP_PAIRS * WAVE), 0, s, A, Bt, Pt, Wp, ldw, \
                                         bias, c0, h, c_last, B, S, d, shift_on)
             if (act == DMN_ACT_TANH) DMN_MM(DMN_ACT_TANH);

@@ -479,8 +479,8 @@ def test_hot_path_matches_reference_golden(name):
                                        # 64-byte-aligned (shifted) column windows, incl. windows that start below column 0
                                        (16, 20, 10, 3, 1005), (32, 20, 10, 2, 1005), (2, 20, 10, 4, 1000), (4, 20, 10, 2, 100),
                                        # ... the matrix-core kernel (blocks of 32 steps, super-blocks of 8 pixels): one and
-                                       # several whole super-blocks, ragged last window; S % 8 != 0 stays on the VALU pair
-                                       # kernel whatever DMN_MIX_SRU_MFMA says (a generic-S variant was measured: no faster)
+                                       # several whole super-blocks, ragged last window, and partial last super-blocks
+                                       # (S % 8 = 1 .. 7: the end falls in every block and on different 4-step groups)
                                        (2, 20, 10, 8, 64), (1, 20, 10, 16, 1005), (3, 20, 10, 24, 1000), (16, 20, 10, 8, 1005),
                                        (5, 20, 10, 8, 70), (2, 20, 10, 9, 64), (1, 20, 10, 13, 130), (2, 20, 10, 18, 70),
                                        (1, 20, 10, 5, 64), (2, 20, 10, 6, 100), (1, 20, 10, 7, 64), (1, 20, 10, 23, 64)])
