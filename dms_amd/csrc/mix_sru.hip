@@ -477,7 +477,6 @@ mix_sru_mfma_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
     __syncthreads();
     const float bg2 = -MS_LOG2E * bias[j + role * d];
     const float *Ab = A + (long long)b * S * M4;
-    const float *pb = Pt + (long long)b * S * (KX * LX) + n32 * KX + hf;   // P[t = n32, k = hf] of the sample
     float cur = (role == 0 && c0) ? c0[col] : 0.0f;
     float *hp = h + col;
     const long long hstride = (long long)B * d;
@@ -489,6 +488,30 @@ mix_sru_mfma_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
     // One super-block.  TAIL: the last, partial one when S is not a multiple of 8 -- its own copy of the code,
     // run once: pixels / P rows past the end are clamped (their tile rows are never read out), blocks and
     // 4-step groups past the end are skipped by both roles alike (20 steps per pixel: the end is on a group).
+    // Both operand streams are fetched one stage ahead -- the block's P rows during the previous block, the
+    // super-block's A during the previous super-block -- so their latency passes under the scan instead of in
+    // front of the MFMAs.  Rows / pixels past the end are clamped (fetched, never used).
+    float pa_nx[KX / 2];
+    float2 av_nx[2][PIX];
+    const float *prow = Pt + (long long)b * Ttot * KX + hf;
+    auto fetch_p = [&](long long T0n) {
+        long long tr = T0n + n32;
+        tr = tr < Ttot ? tr : Ttot - 1;
+#pragma unroll
+        for (int jj = 0; jj < KX / 2; ++jj) pa_nx[jj] = prow[tr * KX + 2 * jj];
+    };
+    auto fetch_a = [&](int sbn) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int px = 0; px < PIX; ++px) {
+                int sp = sbn * PIX + px;
+                sp = sp < S ? sp : S - 1;
+                av_nx[st][px] = *reinterpret_cast<const float2 *>(Ab + (long long)sp * M4 + 4 * jset[st] + g0);
+            }
+    };
+    fetch_a(0);
+    fetch_p(0);
     auto super_block = [&](int sb, auto tailc) {
         constexpr bool TAIL = decltype(tailc)::value != 0;
         const int nst = TAIL ? (S - sb * PIX) * LX : PIX * LX;                 // steps of this super-block
@@ -498,12 +521,10 @@ mix_sru_mfma_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
         for (int st = 0; st < 2; ++st)
 #pragma unroll
             for (int px = 0; px < PIX; ++px) {
-                int sp = sb * PIX + px;
-                if (TAIL) sp = sp < S ? sp : S - 1;
-                const float2 v = *reinterpret_cast<const float2 *>(Ab + (long long)sp * M4 + 4 * jset[st] + g0);
-                av[st][0][px] = v.x;
-                av[st][1][px] = v.y;
+                av[st][0][px] = av_nx[st][px].x;
+                av[st][1][px] = av_nx[st][px].y;
             }
+        if constexpr (!TAIL) fetch_a(sb + 1);
         static_for_t<0, NBLK>([&](auto bc) {
             constexpr int blk = decltype(bc)::value;
             if constexpr (TAIL) {
@@ -511,15 +532,9 @@ mix_sru_mfma_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
             }
             const long long T0 = (long long)sb * (PIX * LX) + blk * BLK;       // first step of the block
             float pa[KX / 2];
-            if constexpr (TAIL) {
-                const long long tr = T0 + n32 < Ttot ? T0 + n32 : Ttot - 1;
-                const float *pr = Pt + ((long long)b * Ttot + tr) * KX + hf;
 #pragma unroll
-                for (int jj = 0; jj < KX / 2; ++jj) pa[jj] = pr[2 * jj];
-            } else {
-#pragma unroll
-                for (int jj = 0; jj < KX / 2; ++jj) pa[jj] = pb[T0 * KX + 2 * jj];
-            }
+            for (int jj = 0; jj < KX / 2; ++jj) pa[jj] = pa_nx[jj];
+            fetch_p(T0 + BLK);
             f32x16m_t acc[2][2];
             static_for_t<0, 4>([&](auto qc) {
                 constexpr int q4 = decltype(qc)::value;
@@ -585,7 +600,12 @@ mix_sru_mfma_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
                 });
             } else {
                 const float *hb = &hand[parity][0][lane];
-                float *hs = hp + T0 * hstride;
+                // the block's first row through an OPAQUE uniform offset: the 32 row offsets below then stay the same
+                // 32 values for every block (un-fenced, hipcc folds the block offset in and keeps 160 64-bit
+                // constants in spilled SGPRs; fencing the POINTER instead would turn the stores into flat stores)
+                long long hoff = T0 * hstride;
+                asm volatile("" : "+s"(hoff));
+                float *hs = hp + hoff;
                 static_for_t<0, BLK / 4>([&](auto gc) {
                     constexpr int i0 = decltype(gc)::value * 4;
                     if constexpr (TAIL) {
