@@ -15,7 +15,7 @@
 //
 // The arithmetic repeats dmn_mix_bcast_add's and dmn_sru_fwd's operation for operation (same
 // order of the additions and FMAs, same gate formulas), so h is bit-identical to the unfused path.
-#include "common.h"
+#include "sru_ring.h"
 
 namespace dmn {
 
@@ -478,8 +478,8 @@ mix_sru_mfma_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
     const float bg2 = -MS_LOG2E * bias[j + role * d];
     const float *Ab = A + (long long)b * S * M4;
     float cur = (role == 0 && c0) ? c0[col] : 0.0f;
-    float *hp = h + col;
     const long long hstride = (long long)B * d;
+    const int hvoff = col * 4, hrowB = B * d * 4;             // bytes (the host checks 32 rows < 2 GiB)
 #define DMN_MM_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
     const long long Ttot = (long long)S * LX;
@@ -600,12 +600,9 @@ mix_sru_mfma_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
                 });
             } else {
                 const float *hb = &hand[parity][0][lane];
-                // the block's first row through an OPAQUE uniform offset: the 32 row offsets below then stay the same
-                // 32 values for every block (un-fenced, hipcc folds the block offset in and keeps 160 64-bit
-                // constants in spilled SGPRs; fencing the POINTER instead would turn the stores into flat stores)
-                long long hoff = T0 * hstride;
-                asm volatile("" : "+s"(hoff));
-                float *hs = hp + hoff;
+                // h rows through a buffer descriptor re-based on the block's first row (uniform): per-lane byte
+                // offset of the column + a uniform row offset in an SGPR -- no 64-bit address arithmetic per store
+                const rsrc_t rH = make_rsrc(h + T0 * hstride);
                 static_for_t<0, BLK / 4>([&](auto gc) {
                     constexpr int i0 = decltype(gc)::value * 4;
                     if constexpr (TAIL) {
@@ -621,7 +618,7 @@ mix_sru_mfma_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const float hv = __builtin_fmaf(ac_t[i] - q[1][i0 + i], r[i], q[1][i0 + i]);
-                        __builtin_nontemporal_store(hv, hs + (long long)(i0 + i) * hstride);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hv), rH, hvoff, (i0 + i) * hrowB, DMN_ST_AUX);
                     }
                 });
             }
@@ -668,7 +665,7 @@ extern "C" int dmn_mix_sru_fwd(const float *A, const float *Bt, const float *Pt,
         // kernel).  147 VGPRs and 72 KB of LDS: two workgroups share a CU from B = 64 on (measured at S = 256:
         // 0.354 vs 0.411 ms at B = 32, 0.630 vs 0.760 at B = 64).
         const char *me = getenv("DMN_MIX_SRU_MFMA");
-        if (!(((uintptr_t)A | (uintptr_t)Bt) & 7) && !(me && atoi(me) == 0)) {
+        if (!(((uintptr_t)A | (uintptr_t)Bt) & 7) && (long long)B * d * 4 * 33 < (1LL << 31) && !(me && atoi(me) == 0)) {
 #define DMN_MM(ACTV) hipLaunchKernelGGL((mix_sru_mfma_kernel<ACTV>), pgrid, dim3(2 * MP_PAIRS * WAVE), 0, s, A, Bt, Pt, Wp, ldw, \
                                         bias, c0, h, c_last, B, S, d, shift_on)
             if (act == DMN_ACT_TANH) DMN_MM(DMN_ACT_TANH);
