@@ -34,11 +34,11 @@ from ..sru import SRU
 from .dpn import create_backbone
 
 
-# ops.mix_sru_fwd is bound by its waves' dependent chains (~0.41-0.43 ms at T = 5120 however few columns:
-# two cooperating waves per 64 columns, round 2), the mix + scan pair is HBM-bound and shrinks with the
-# batch: measured cross-over on MI355X (tools/mix_sru_bench.py) at 8 samples of 1005 columns
-# (B=4: 0.27 vs 0.41 ms, B=8: 0.45 vs 0.41, B=12: 0.56 vs 0.41, B=16: 0.66 vs 0.41, B=32: 1.30 vs 0.43)
-MIX_SCAN_MIN_COLS = 8000
+# ops.mix_sru_fwd is bound by its waves' issue, not by HBM (~0.32-0.33 ms at T = 5120 however few columns:
+# two cooperating waves per 64 columns, rank-10 update on the matrix cores, round 2), the mix + scan pair is
+# HBM-bound and shrinks with the batch: measured cross-over on MI355X (tools/mix_sru_bench.py) between 5 and 6
+# samples of 1005 columns (B=4: 0.26 vs 0.32 ms, B=8: 0.45 vs 0.32, B=16: 0.66 vs 0.32, B=32: 1.30 vs 0.33)
+MIX_SCAN_MIN_COLS = 6000
 
 _LOG = logging.getLogger("dms_amd")
 

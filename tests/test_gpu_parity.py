@@ -544,7 +544,7 @@ def test_folded_layer0_projection_equals_unfused_path():
     with torch.no_grad():
         assert net.fold_comb_into_msru and net.mrnn.rnn_lst[0].k == 4
         a = net.hot_path(vis.to(DEV), lang.to(DEV)).cpu()
-        # the same with the mix fused into the layer-0 scan (taken by itself from ~12 samples on)
+        # the same with the mix fused into the layer-0 scan (taken by itself from 6 samples on)
         import dms_amd.models.dmn as dmn_mod
         keep = dmn_mod.MIX_SCAN_MIN_COLS
         dmn_mod.MIX_SCAN_MIN_COLS = 0
