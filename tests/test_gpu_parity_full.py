@@ -246,6 +246,34 @@ def test_sru_bwd_shape_fuzz_matches_oracle(T, B, d, k, act, scale_x, seed):
         np.testing.assert_allclose(xg.grad.cpu().numpy(), gx_r, rtol=2e-4, atol=1e-5)
 
 
+@settings(max_examples=30, deadline=None, derandomize=True,
+          suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(B=st.integers(1, 5), S=st.integers(1, 41), d=st.integers(1, 200), model_shape=st.booleans(),
+       act=st.sampled_from(["tanh", "relu", "identity"]), with_c0=st.booleans(), seed=st.integers(0, 10 ** 6))
+def test_mix_sru_fwd_shape_fuzz_is_bit_identical_to_mix_then_scan(B, S, d, model_shape, act, with_c0, seed):
+    """dmn_mix_sru_fwd over odd shapes: the model's K = 10 / L = 20 (the two-wave kernels: VALU and matrix-core
+    variant, partial last super-blocks, ragged and shifted column windows) and other K / L (single-wave kernel).
+    Every variant must reproduce dmn_mix_bcast_add + dmn_sru_fwd bit for bit."""
+    L, K = (20, 10) if model_shape else (1 + seed % 7, 1 + seed % 12)
+    M4 = 4 * d
+    A = det_uniform((B, S, M4), seed, 1.0).to(DEV)
+    Bt = det_uniform((L, B, M4), seed + 1, 1.0).to(DEV)
+    P = det_uniform((L, B, K, S), seed + 2, 1.0).to(DEV)
+    Wp = det_uniform((M4, K), seed + 3, 0.5).to(DEV)
+    bias = det_uniform((2 * d,), seed + 4, 0.5).to(DEV)
+    c0 = det_uniform((B, d), seed + 5, 1.0).to(DEV) if with_c0 else None
+    U0 = ops.mix_bcast_add(A, Bt, P, Wp).view(S * L, B, d, 4)
+    h_ref, _, c_ref = ops.sru_forward_raw(U0, None, bias, c0, act, 1.0, nchunks=1)
+    for force in (None, "0", "1"):
+        if force is not None:
+            os.environ["DMN_MIX_SRU_MFMA"] = force
+        try:
+            h, c = ops.mix_sru_fwd(A, Bt, P, Wp, bias, c0, act)
+        finally:
+            os.environ.pop("DMN_MIX_SRU_MFMA", None)
+        assert torch.equal(h, h_ref) and torch.equal(c, c_ref), "DMN_MIX_SRU_MFMA=%s" % force
+
+
 @pytest.mark.parametrize("use_tanh,use_relu,scale_x", [(0, 0, 1.0), (0, 1, 1.7), (1, 0, 0.5)])
 def test_sru_module_with_other_activation_and_highway_scale_matches_oracle(use_tanh, use_relu, scale_x):
     """The upstream unknowns as MODULE options (use_tanh / use_relu / scale_x), fwd + autograd."""
