@@ -41,15 +41,20 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
 SEED = 1111                    # reference default seed (train.py:75)
 
 
+# the mSRU entry points: timed with HIP events inside the timed region (the roofline kernel is one of them)
+MSRU_ENTRY_POINTS = frozenset(["dmn_sru_fwd", "dmn_sru_fwd_scan", "dmn_sru_state_fwd", "dmn_mix_sru_fwd"])
+
+
 class LaunchTimer(object):
     """Brackets every libdmn_hip entry-point call with HIP events on the launch stream."""
 
     def __init__(self):
         self.records = []
         self.enabled = False
+        self.only = None                 # None: every entry point; else a set of entry-point names
 
     def begin(self, name, args):
-        if not self.enabled:
+        if not self.enabled or (self.only is not None and name not in self.only):
             return None
         a = torch.cuda.Event(enable_timing=True)
         a.record()
@@ -562,7 +567,11 @@ def main():
             out = net(img, words)
         torch.cuda.synchronize()
         barrier()
+        # inside the timed region only the mSRU launches (the `roofline` kernel among them) are bracketed
+        # with HIP events; the table of all ~150 entry-point calls per step comes from extra steps after it
+        # (300 event records per step cost the step ~0.5 %: DMN_BENCH_TIMER_ALL=1 brings them back)
         timer.records = []
+        timer.only = None if os.environ.get("DMN_BENCH_TIMER_ALL") == "1" else MSRU_ENTRY_POINTS
         timer.enabled = True
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -571,6 +580,15 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         timer.enabled = False
+        timed_records = timer.records
+        table_steps = args.steps
+        if timer.only is not None:
+            timer.records, timer.only, timer.enabled = [], None, True
+            table_steps = min(args.steps, 5)
+            for _ in range(table_steps):
+                out = net(img, words)
+            torch.cuda.synchronize()
+            timer.enabled = False
     assert tuple(out.shape) == (B, 1, 512, 512) and bool(torch.isfinite(out).all())
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
@@ -579,14 +597,16 @@ def main():
     elapsed = float(el.item())
     qps = world * B * args.steps / elapsed
 
-    kernels = timer.summary()
-    scans = [r for r in kernels if r["kernel"].startswith("sru_fwd") and "T=%d" % (256 * 20) in r["kernel"]]
-    dom = scans[0] if scans else kernels[0]
+    kernels = timer.summary()                       # every entry point (the extra steps, or the timed region)
+    timer.records = timed_records
+    timed = timer.summary()                         # the timed region's own records: roofline comes from here
+    scans = [r for r in timed if r["kernel"].startswith("sru_fwd") and "T=%d" % (256 * 20) in r["kernel"]]
+    dom = scans[0] if scans else timed[0]
     roofline = {"bound": "hbm", "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": dom["frac_of_8TBs"], "traffic": measured_traffic(dom["kernel"]),
                 "kernel": dom["kernel"], "avg_launch_ms": dom["avg_ms"],
                 "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"]}
-    hip_ms = sum(r["total_ms"] for r in kernels) / args.steps
+    hip_ms = sum(r["total_ms"] for r in kernels) / table_steps
 
     line = {"metric": "queries/sec (whole node) high-res 512px DMN inference; mSRU achieved HBM GB/s",
             "value": round(qps, 3), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
@@ -602,6 +622,9 @@ def main():
             "msru_GBs": dom["achieved_GBs"],
             "gemm_table_entries": gemm_table_entries,
             "hip_kernels_ms_per_step": round(hip_ms, 3),
+            "hip_kernels_from": ("the timed region" if os.environ.get("DMN_BENCH_TIMER_ALL") == "1" else
+                                 "%d extra steps after the timed region (inside it only the mSRU launches carry "
+                                 "HIP events)" % table_steps),
             "hip_kernels": kernels}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
