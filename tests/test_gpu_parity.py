@@ -1007,23 +1007,25 @@ def test_dmn_every_inference_shortcut_equals_the_plain_path(high_res, size):
     assert ((fast > 0) == (plain > 0)).float().mean().item() >= 0.999
 
 
-def test_graphed_dmn_replay_equals_eager_forward():
+@pytest.mark.parametrize("B,n_words", [(2, 6), (8, 20)])
+def test_graphed_dmn_replay_equals_eager_forward(B, n_words):
     """One captured HIP graph per shape: replays must reproduce the eager forward bit for bit,
-    for new inputs as well (static buffers), and reject other shapes."""
+    for new inputs as well (static buffers), and reject other shapes.  (8 queries of 20 words: the
+    forward contains the fused mix + layer-0 scan on the matrix cores, captured like any other launch.)"""
     net = dms_amd.DMN(100, num_filters=10, lang_layers=3, mix_we=True, pretrained=False,
                       high_res=True, upsampling_mode="bilinear", upsampling_amplification=32)
     torch.nn.Module.load_state_dict(net, det_fill_state(net.state_dict()))
     net = net.to(DEV).eval()
-    g = dms_amd.GraphedDMN(net, 2, 64, 96, 6)
+    g = dms_amd.GraphedDMN(net, B, 64, 96, n_words)
     for seed in (11, 12):
-        img = det_uniform((2, 3, 64, 96), seed, 1.0).to(DEV)
-        words = det_ints((2, 6), seed + 100, 100).to(DEV)
+        img = det_uniform((B, 3, 64, 96), seed, 1.0).to(DEV)
+        words = det_ints((B, n_words), seed + 100, 100).to(DEV)
         with torch.no_grad():
             want = net(img, words)
         got = g(img, words).clone()
-        assert got.shape == (2, 1, 64, 96) and torch.equal(got, want)
+        assert got.shape == (B, 1, 64, 96) and torch.equal(got, want)
     with pytest.raises(RuntimeError, match="captured for"):
-        g(torch.zeros((1, 3, 64, 96), device=DEV), torch.zeros((1, 6), dtype=torch.long, device=DEV))
+        g(torch.zeros((1, 3, 64, 96), device=DEV), torch.zeros((1, n_words), dtype=torch.long, device=DEV))
 
 
 # ------------------------------------------------------------------------------------
