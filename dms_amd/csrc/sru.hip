@@ -27,13 +27,13 @@ namespace dmn {
 void launch_sru_fwd_k3(int act, bool store_c, int depth, dim3 grid, hipStream_t s, const float *U,
                        const float *x, const float *bias, const float *c0, float *h, float *c_all,
                        float *c_last, int T, int ncols, int d, float scale_x, int h_t0,
-                       int chunk_len, const float2 *carries);
+                       int chunk_len, const float2 *carries, int blk0 = 0);
 void launch_sru_fwd_k4(int act, bool store_c, int depth, dim3 grid, hipStream_t s, const float *U,
                        const float *x, const float *bias, const float *c0, float *h, float *c_all,
                        float *c_last, int T, int ncols, int d, float scale_x, int h_t0,
-                       int chunk_len, const float2 *carries);
+                       int chunk_len, const float2 *carries, int blk0 = 0);
 void launch_sru_fwd_k2(int depth, dim3 grid, hipStream_t s, const float *U, const float *bias,
-                       const float *c0, float *c_all, float *c_last, int T, int ncols, int d);
+                       const float *c0, float *c_all, float *c_last, int T, int ncols, int d, int blk0 = 0);
 constexpr int WHOLE_SEQUENCE = 0x7fffffff / 2;   // chunk_len of the un-chunked scan
 
 
@@ -150,12 +150,24 @@ extern "C" int dmn_sru_fwd(const float *U, const float *x, const float *bias, co
     if (!h && h_t0 < T) return fail(-1, "dmn_sru_fwd: h must not be NULL");
     const int ncols = B * d;
     const int nwaves = (ncols + WAVE - 1) / WAVE;
-    int depth = depth_override();
-    if (depth <= 0) depth = pick_depth(nwaves, c_all != nullptr || 2 * (long long)h_t0 < T, k == 3 ? 2 : 1, c_all ? 2 : 1);
-    dim3 grid(nwaves);
     hipStream_t s = (hipStream_t)stream;
-    if (k == 3) launch_sru_fwd_k3(act, c_all != nullptr, depth, grid, s, U, x, bias, c0, h, c_all, c_last, T, ncols, d, scale_x, h_t0, WHOLE_SEQUENCE, nullptr);
-    else        launch_sru_fwd_k4(act, c_all != nullptr, depth, grid, s, U, x, bias, c0, h, c_all, c_last, T, ncols, d, scale_x, h_t0, WHOLE_SEQUENCE, nullptr);
+    const bool stores = c_all != nullptr || 2 * (long long)h_t0 < T;
+    // A scan that stores every step streams best with about one wave per SIMD and a deep ring (1005 waves:
+    // 73 % of 8 TB/s); two waves per SIMD were 67 % at the best depth (3).  So a wide scan (configs[4]: 2000
+    // waves) goes out as consecutive column ranges of <= 4 * NUM_CU waves each (DMN_SRU_SPLIT=0: one launch).
+    int parts = 1;
+    const char *sp = getenv("DMN_SRU_SPLIT");
+    if (stores && nwaves >= 6 * NUM_CU && !(sp && atoi(sp) == 0)) parts = (nwaves + 4 * NUM_CU - 1) / (4 * NUM_CU);
+    if (sp && atoi(sp) > 1) parts = atoi(sp);                  // (A/B runs: force the number of ranges)
+    const int per = (nwaves + parts - 1) / parts;
+    for (int blk0 = 0; blk0 < nwaves; blk0 += per) {
+        const int nw = nwaves - blk0 < per ? nwaves - blk0 : per;
+        int depth = depth_override();
+        if (depth <= 0) depth = pick_depth(nw, stores, k == 3 ? 2 : 1, c_all ? 2 : 1);
+        dim3 grid(nw);
+        if (k == 3) launch_sru_fwd_k3(act, c_all != nullptr, depth, grid, s, U, x, bias, c0, h, c_all, c_last, T, ncols, d, scale_x, h_t0, WHOLE_SEQUENCE, nullptr, blk0);
+        else        launch_sru_fwd_k4(act, c_all != nullptr, depth, grid, s, U, x, bias, c0, h, c_all, c_last, T, ncols, d, scale_x, h_t0, WHOLE_SEQUENCE, nullptr, blk0);
+    }
     return launch_status("dmn_sru_fwd");
 }
 

@@ -205,9 +205,10 @@ sru_fwd_cols(const float *__restrict__ U, const float *__restrict__ x,
              const float *__restrict__ bias, const float *__restrict__ c0,
              float *__restrict__ h, float *__restrict__ c_all, float *__restrict__ c_last,
              int T_total, int ncols, int d, float scale_x, int h_t0,
-             int chunk_len, const float2 *__restrict__ carries)
+             int chunk_len, const float2 *__restrict__ carries, int blk0)
 {
-    const int col = blockIdx.x * WAVE + threadIdx.x;
+    // blk0: first 64-column block of this launch (a wide scan is launched in column ranges, see dmn_sru_fwd)
+    const int col = (blk0 + (int)blockIdx.x) * WAVE + threadIdx.x;
     if (col >= ncols) return;
     const int j = col % d;
     const float bf2 = -LOG2E * bias[j], br2 = -LOG2E * bias[j + d];
@@ -249,11 +250,11 @@ template <int K, int ACT, bool STORE_C>
 static void launch_fwd(int depth, dim3 grid, hipStream_t s, const float *U, const float *x,
                        const float *bias, const float *c0, float *h, float *c_all, float *c_last,
                        int T, int ncols, int d, float scale_x, int h_t0, int chunk_len,
-                       const float2 *carries)
+                       const float2 *carries, int blk0)
 {
 #define DMN_FWD(DEP)                                                                              \
     hipLaunchKernelGGL((sru_fwd_cols<K, ACT, DEP, STORE_C>), grid, dim3(WAVE), 0, s, U, x, bias, \
-                       c0, h, c_all, c_last, T, ncols, d, scale_x, h_t0, chunk_len, carries)
+                       c0, h, c_all, c_last, T, ncols, d, scale_x, h_t0, chunk_len, carries, blk0)
     if (depth <= 3) DMN_FWD(3);
     else if (depth <= 4) DMN_FWD(4);
     else if (depth <= 6) DMN_FWD(6);
@@ -268,37 +269,37 @@ template <int K, bool STORE_C>
 static void launch_fwd_act(int act, int depth, dim3 grid, hipStream_t s, const float *U,
                            const float *x, const float *bias, const float *c0, float *h,
                            float *c_all, float *c_last, int T, int ncols, int d, float scale_x,
-                           int h_t0, int chunk_len, const float2 *carries)
+                           int h_t0, int chunk_len, const float2 *carries, int blk0)
 {
     if (act == DMN_ACT_TANH)
-        launch_fwd<K, DMN_ACT_TANH, STORE_C>(depth, grid, s, U, x, bias, c0, h, c_all, c_last, T, ncols, d, scale_x, h_t0, chunk_len, carries);
+        launch_fwd<K, DMN_ACT_TANH, STORE_C>(depth, grid, s, U, x, bias, c0, h, c_all, c_last, T, ncols, d, scale_x, h_t0, chunk_len, carries, blk0);
     else if (act == DMN_ACT_RELU)
-        launch_fwd<K, DMN_ACT_RELU, STORE_C>(depth, grid, s, U, x, bias, c0, h, c_all, c_last, T, ncols, d, scale_x, h_t0, chunk_len, carries);
+        launch_fwd<K, DMN_ACT_RELU, STORE_C>(depth, grid, s, U, x, bias, c0, h, c_all, c_last, T, ncols, d, scale_x, h_t0, chunk_len, carries, blk0);
     else
-        launch_fwd<K, DMN_ACT_IDENTITY, STORE_C>(depth, grid, s, U, x, bias, c0, h, c_all, c_last, T, ncols, d, scale_x, h_t0, chunk_len, carries);
+        launch_fwd<K, DMN_ACT_IDENTITY, STORE_C>(depth, grid, s, U, x, bias, c0, h, c_all, c_last, T, ncols, d, scale_x, h_t0, chunk_len, carries, blk0);
 }
 
 #if DMN_SRU_K == 2
 // state-only: no h, no c_all, the activation is never applied; the caller passes h_t0 = T
 void DMN_SRU_LAUNCH_NAME(int depth, dim3 grid, hipStream_t s, const float *U, const float *bias,
-                         const float *c0, float *c_all, float *c_last, int T, int ncols, int d)
+                         const float *c0, float *c_all, float *c_last, int T, int ncols, int d, int blk0)
 {
     // c_all != NULL (training): every step's cell state is kept for the backward scan
     if (c_all)
         launch_fwd<2, DMN_ACT_IDENTITY, true>(depth, grid, s, U, nullptr, bias, c0, nullptr, c_all,
-                                              c_last, T, ncols, d, 1.0f, T, 0x7fffffff / 2, nullptr);
+                                              c_last, T, ncols, d, 1.0f, T, 0x7fffffff / 2, nullptr, blk0);
     else
         launch_fwd<2, DMN_ACT_IDENTITY, false>(depth, grid, s, U, nullptr, bias, c0, nullptr, nullptr,
-                                               c_last, T, ncols, d, 1.0f, T, 0x7fffffff / 2, nullptr);
+                                               c_last, T, ncols, d, 1.0f, T, 0x7fffffff / 2, nullptr, blk0);
 }
 #else
 void DMN_SRU_LAUNCH_NAME(int act, bool store_c, int depth, dim3 grid, hipStream_t s, const float *U,
                          const float *x, const float *bias, const float *c0, float *h,
                          float *c_all, float *c_last, int T, int ncols, int d, float scale_x,
-                         int h_t0, int chunk_len, const float2 *carries)
+                         int h_t0, int chunk_len, const float2 *carries, int blk0)
 {
-    if (store_c) launch_fwd_act<DMN_SRU_K, true>(act, depth, grid, s, U, x, bias, c0, h, c_all, c_last, T, ncols, d, scale_x, h_t0, chunk_len, carries);
-    else         launch_fwd_act<DMN_SRU_K, false>(act, depth, grid, s, U, x, bias, c0, h, c_all, c_last, T, ncols, d, scale_x, h_t0, chunk_len, carries);
+    if (store_c) launch_fwd_act<DMN_SRU_K, true>(act, depth, grid, s, U, x, bias, c0, h, c_all, c_last, T, ncols, d, scale_x, h_t0, chunk_len, carries, blk0);
+    else         launch_fwd_act<DMN_SRU_K, false>(act, depth, grid, s, U, x, bias, c0, h, c_all, c_last, T, ncols, d, scale_x, h_t0, chunk_len, carries, blk0);
 }
 #endif
 

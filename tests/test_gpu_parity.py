@@ -52,6 +52,40 @@ ACTS = ["tanh", "relu", "identity"]     # upstream's use_tanh / use_relu switche
 SCALES = [1.0, 1.7]                     # upstream's highway scale_x (applies to k == 3 only)
 
 
+@pytest.mark.parametrize("k", [3, 4])
+@pytest.mark.parametrize("want_c", [False, True])
+def test_sru_fwd_wide_scan_in_column_ranges_equals_one_launch(k, want_c):
+    """From 1536 wavefronts on a scan that stores every step is launched as consecutive column ranges
+    (dmn_sru_fwd); the ranges must tile the columns exactly: same bits as one launch, ragged last range."""
+    T, B, d = 9, 99, 1003                                     # 99 297 columns = 1552 wavefronts, the last one partial
+    u = det_uniform((T, B, d, k), 901, 1.5).to(DEV)
+    x = det_uniform((T, B, d), 902, 1.0).to(DEV) if k == 3 else None
+    bias = det_uniform((2 * d,), 903, 0.5).to(DEV)
+    c0 = det_uniform((B, d), 904, 1.0).to(DEV)
+    outs = []
+    for split in ("0", None, "3", "7"):
+        if split is not None:
+            os.environ["DMN_SRU_SPLIT"] = split
+        try:
+            outs.append(ops.sru_forward_raw(u, x, bias, c0, "tanh", 1.0, 0, want_c=want_c, nchunks=1))
+        finally:
+            os.environ.pop("DMN_SRU_SPLIT", None)
+    h0, c_all0, cl0 = outs[0]
+    for h, c_all, cl in outs[1:]:
+        assert torch.equal(h, h0) and torch.equal(cl, cl0)
+        if want_c:
+            assert torch.equal(c_all, c_all0)
+    # a few columns against the oracle (first, around the range boundaries of the default split, last)
+    cols = [0, 1, 49663, 49664, 49665, B * d - 2, B * d - 1]
+    uu = u.view(T, B * d, k)[:, cols].cpu().numpy().reshape(T, 1, len(cols), k)
+    xx = None if x is None else x.view(T, B * d)[:, cols].cpu().numpy().reshape(T, 1, len(cols))
+    jj = [c % d for c in cols]
+    bb = np.concatenate([bias.cpu().numpy()[jj], bias.cpu().numpy()[[d + j for j in jj]]])
+    h_o, _, cl_o = sru_ref.sru_fwd_c(uu, xx, bb, c0.view(-1)[cols].cpu().numpy().reshape(1, -1), "tanh", 1.0)
+    np.testing.assert_allclose(h0.view(T, B * d)[:, cols].cpu().numpy(), h_o[:, 0], rtol=1e-4, atol=3e-6)
+    np.testing.assert_allclose(cl0.view(-1)[cols].cpu().numpy(), cl_o[0], rtol=1e-4, atol=3e-6)
+
+
 @pytest.mark.parametrize("T,B,d,k", SRU_SHAPES)
 @pytest.mark.parametrize("act", ACTS)
 @pytest.mark.parametrize("scale_x", SCALES)
