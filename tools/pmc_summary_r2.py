@@ -29,7 +29,8 @@ LABELS = {
     ("dmn::sru_fwd_cols<3, 1, 16, false>", 32192): ("sru_fwd k=3 T=5120 cols=32160", 20 * E),
     ("dmn::sru_fwd_cols<4, 1, 16, false>", 32192): ("sru_fwd k=4 T=5120 cols=32160", 20 * E),
     ("dmn::sru_fwd_cols<3, 1, 32, false>", 32192): ("sru_fwd k=3 T=5120 cols=32160 tail", 16 * E + 4 * 256 * 32160),
-    ("dmn::sru_fwd_cols<3, 1, 3, false>", 128000): ("sru_fwd k=3 T=4096 cols=128000", 20 * 4096 * 128000),
+    # configs[4] goes out as two column ranges of 1000 wavefronts (dmn_sru_fwd): HALF the entry point's bytes per launch
+    ("dmn::sru_fwd_cols<3, 1, 8, false>", 64000): ("sru_fwd k=3 T=4096 cols=128000", 20 * 4096 * 128000, 2),
     ("dmn::sru_fwd_cols<2, 0, 32, false>", 32192): ("sru_state (u0|f only) T=4864 cols=32160", 8 * 4864 * 32160 + 4 * 32160),
     ("dmn::sru_fwd_cols<3, 1, 8, true>", 64320): ("sru_fwd k=3 T=2000 cols=64320", 24 * EB),
     ("dmn::sru_fwd_cols<4, 1, 8, true>", 64320): ("sru_fwd k=4 T=2000 cols=64320", 24 * EB),
@@ -43,11 +44,15 @@ out = {"_how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate pass
                "Units KiB, median of the launches; hbm_bytes = 2 x FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE reports "
                "half of a wide streaming read; WRITE_SIZE exact).  The fused mix+scan kernel re-reads small L2-resident "
                "operands (Bt, P, Wp) that the x2 rule over-counts: its WRITE_SIZE alone is +2.4 % over the h bytes (VALU pair kernel +0.7 %, round 1 single-wave kernel +11 %)."}
-for key, (label, alg) in LABELS.items():
+for key, spec in LABELS.items():
+    label, alg = spec[0], spec[1]
+    launches = spec[2] if len(spec) > 2 else 1          # launches per entry-point call
     if key in fetch and key in write:
-        hb = int(round((2 * fetch[key] + write[key]) * 1024))
+        hb = int(round((2 * fetch[key] + write[key]) * 1024)) * launches
         out[label] = {"fetch_size_kib": round(fetch[key], 1), "write_size_kib": round(write[key], 1),
                       "hbm_bytes": hb, "algorithmic_bytes": alg, "ratio": round(hb / alg, 4)}
+        if launches > 1:
+            out[label]["launches_per_call"] = launches
 # tap_gather levels, labelled as bench.py names them (W = 256: Cout = 1)
 for W, co in ((16, 512), (32, 256), (64, 128), (128, 64), (256, 1)):
     kf = [k for k in fetch if k[0].startswith("dmn::tap_gather_tile_kernel<%d," % W) and k in write]
