@@ -7,9 +7,14 @@
 Workload `dmn512` (default) = BASELINE.json configs[1]: DMN high-res 512 px inference
 (dpn92, num_filters 10, lang_layers 3, mix_we, upsampling amplification 32, random init,
 20-token synthetic queries), batch 32 per GPU, inputs resident in HBM before the timed
-region.  A step = one forward over one batch.  N > 1: one process per GPU (torchrun), the
-batch of (image, query) pairs is sharded, no data-path collective ("weak" scaling: 32 per
-GPU, so N = 8 is configs[2]'s 256).  value = total queries / max-over-ranks wall time.
+region.  A step = one forward over one batch.  N > 1: one process per GPU, the batch of
+(image, query) pairs is sharded, no data-path collective ("weak" scaling: 32 per GPU, so
+N = 8 is configs[2]'s 256).  value = total queries / max-over-ranks wall time.  The ranks come
+from torchrun's environment; started WITHOUT it (`python bench.py --gpus N`), this process
+starts the N ranks itself as a `torch.distributed.run` child before it makes any GPU call, and
+fails loudly when the box has fewer than N devices.  `n_gpus` in the line is
+dist.get_world_size() and `collective_ranks` the result of a one-element all-reduce over the
+job's backend (RCCL), i.e. the number of ranks the collective library really saw.
 
 The same JSON line carries
   roofline     : the mSRU scan named by the metric -- the longest HBM-bound scan launch of the
@@ -20,6 +25,12 @@ The same JSON line carries
                  same way (plus TFLOP/s for the ones that are issue-bound, not HBM-bound);
   gemm_table_entries : shapes served from the recorded rocBLAS/hipBLASLt solution table
                  (dms_amd/tuning/, look-up only; --no-gemm-table to measure without it);
+  shards       : configs[2]'s per-GPU shards of the global batch 256 -- B = 64 (4 GPUs) and B = 128
+                 (2 GPUs) -- run on this ONE GPU after the timed region: queries/s each and the
+                 difference of samples shared with the B = 32 batch (N = 1 only);
+  train320     : configs[3] on this GPU, bounded (2 warm-up + 3 timed steps at B = 64): ms/step,
+                 samples/s, the backward scan's roofline fraction, loss (N = 1 only; the whole
+                 record comes from --workload train320);
   cpu_baseline : the CPU oracle (oracle/: plain-C scan + pure-torch reference-shaped glue +
                  torch-CPU DPN92) on a bounded sample of the same workload (a few batch-1
                  queries) on this box's host cores -- rank 0, N = 1 only.
@@ -304,20 +315,20 @@ def cpu_baseline_dmn(net, reps, threads):
         # 512 px high-res, batch 8 (backbone and head batched, hot path per sample as in the reference)
         img8 = torch.randn(8, 3, 512, 512, generator=g)
         words8 = torch.randint(0, 1000, (8, 20), generator=g)
-        med8, _ = _median_time(lambda: query(cpu_net, P, cfg, img8, words8), 3)
+        med8, _ = _median_time(lambda: query(cpu_net, P, cfg, img8, words8), 2)
         # configs[0]: 320 px low-res, batch 1 (the reference's own CPU-runnable case)
         low = build_model("cpu", high_res=False)
         Pl = dict(low.state_dict())
         cfgl = dict(cfg, high_res=False)
         img3 = torch.randn(1, 3, 320, 320, generator=g)
-        medl, _ = _median_time(lambda: query(low, Pl, cfgl, img3, words), 5)
+        medl, _ = _median_time(lambda: query(low, Pl, cfgl, img3, words), 3)
     # SRU-only scan, configs[4] scaled to B = 8: T = 4096, d = 1000, k = 3
     T, B, d = 4096, 8, 1000
     rng = np.random.default_rng(SEED)
     u = rng.standard_normal((T, B, d, 3), dtype=np.float32)
     xx = rng.standard_normal((T, B, d), dtype=np.float32)
     bias = (0.1 * rng.standard_normal(2 * d)).astype(np.float32)
-    meds, _ = _median_time(lambda: sru_ref.sru_fwd_c(u, xx, bias, None, "tanh", 1.0, want_c=False), 5)
+    meds, _ = _median_time(lambda: sru_ref.sru_fwd_c(u, xx, bias, None, "tanh", 1.0, want_c=False), 3)
     scan_gbs = 20.0 * T * B * d / meds / 1e9
     cb = {"value": round(1.0 / med, 4), "unit": "queries/s", "cores": threads, "kind": "port",
           "host_cpus": os.cpu_count(), "cpu_model": _cpu_model(), "threads_used": threads,
@@ -327,14 +338,14 @@ def cpu_baseline_dmn(net, reps, threads):
           "seconds_per_query": round(med, 3),
           "cases": {
               "dmn512_highres_b1": {"queries_per_s": round(1.0 / med, 4), "reps": reps},
-              "dmn512_highres_b8": {"queries_per_s": round(8.0 / med8, 4), "reps": 3},
-              "dmn320_lowres_b1 (configs[0])": {"queries_per_s": round(1.0 / medl, 4), "reps": 5},
+              "dmn512_highres_b8": {"queries_per_s": round(8.0 / med8, 4), "reps": 2},
+              "dmn320_lowres_b1 (configs[0])": {"queries_per_s": round(1.0 / medl, 4), "reps": 3},
               "sru_scan_T4096_B8_d1000_k3": {"GBs_algorithmic_20B": round(scan_gbs, 2),
-                                             "ms": round(meds * 1e3, 2), "reps": 5}}}
+                                             "ms": round(meds * 1e3, 2), "reps": 3}}}
     return cb, (img, words, out)
 
 
-def run_train320(args, device, rank, world, timer):
+def run_train320(args, device, rank, world, timer, quiet=False):
     """BASELINE configs[3]: low-res 320 px training step, batch 64 per GPU: forward -> bilinear
     upsample of the logits to the mask size -> BCEWithLogits vs random {0,1} masks
     (train.py:275-283) -> backward -> gradient all-reduce (RCCL) -> Adam(lr 1e-5) (train.py:71,242)."""
@@ -350,7 +361,7 @@ def run_train320(args, device, rank, world, timer):
     def heartbeat():
         while not phase["stop"]:
             time.sleep(20)
-            if not phase["stop"]:
+            if not phase["stop"] and not quiet:
                 print("[train320] rank %d alive: %s (%.0f s)" % (rank, phase["name"], time.perf_counter() - phase["t0"]),
                       file=sys.stderr, flush=True)
 
@@ -402,9 +413,11 @@ def run_train320(args, device, rank, world, timer):
         phase["name"] = "warm-up step %d (MIOpen find / kernel compilation on the first one)" % i
         print("[train320] rank %d starting warm-up step %d" % (rank, i), file=sys.stderr, flush=True)
         arm(wd_first if i == 0 else wd_later)
+        tw = time.perf_counter()
         loss = step()
         torch.cuda.synchronize()
-        print("[train320] rank %d warm-up step %d done" % (rank, i), file=sys.stderr, flush=True)
+        print("[train320] rank %d warm-up step %d done (%.1f s)" % (rank, i, time.perf_counter() - tw),
+              file=sys.stderr, flush=True)
     phase["name"] = "timed steps"
     arm((wd_later * args.steps) if args.warmup else (wd_first + wd_later * args.steps))
     if world > 1:
@@ -452,8 +465,113 @@ def run_train320(args, device, rank, world, timer):
             "allreduce_buckets": (len(red.buckets) if red is not None else None),
             "hip_kernels_ms_per_step": round(sum(r["total_ms"] for r in kernels) / args.steps, 3),
             "hip_kernels": kernels, "loss": float(loss)}
-    if rank == 0:
-        print(json.dumps(line))
+    line.update(_world_proof(device, world))
+    if red is not None:
+        red.remove()
+    return line
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without torchrun's environment: start the N ranks from here, as a
+    `python -m torch.distributed.run` child (the driver's own form of the command), BEFORE this process
+    has made any GPU call -- torch.cuda.device_count() only counts -- and leave with the child's exit
+    code.  Fewer than N devices on the box is an error (unless the one-GPU rehearsal hooks
+    DMN_BENCH_DEVICE / DMN_BENCH_BACKEND pin every rank to one card on purpose)."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if "DMN_BENCH_DEVICE" not in os.environ and have < n:
+        raise SystemExit("bench.py --gpus %d: this box has %d GPU(s); refusing to report an %d-GPU number "
+                         "from fewer devices" % (n, have, n))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] starting %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def _world_proof(device, world):
+    """What the JSON line says about the job's size comes from the process group itself: n_gpus =
+    dist.get_world_size(), collective_ranks = a one-element sum all-reduce over the job's backend."""
+    if not (dist.is_available() and dist.is_initialized()):
+        if world != 1:
+            raise SystemExit("bench.py: %d ranks expected but no process group exists" % world)
+        return {"n_gpus": 1, "collective_ranks": 1, "collective_backend": None}
+    backend = dist.get_backend()
+    one = torch.ones(1, dtype=torch.float32, device=device if backend == "nccl" else "cpu")
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    seen = int(round(float(one.item())))
+    if seen != dist.get_world_size() or seen != world:
+        raise SystemExit("bench.py: the all-reduce saw %d ranks, world size %d, --gpus %d"
+                         % (seen, dist.get_world_size(), world))
+    return {"n_gpus": dist.get_world_size(), "collective_ranks": seen,
+            "collective_backend": "rccl" if backend == "nccl" else backend}
+
+
+def run_shards(net, device, head4, steps=3, warmup=2):
+    """BASELINE configs[2]'s per-GPU shards of the global batch 256 on THIS GPU: B = 64 (the 4-GPU
+    shard) and B = 128 (the 2-GPU shard); B = 32 (8 GPUs) is the headline.  The first 4 samples of
+    each batch are the headline batch's own first 4 (same image, same query), so their logits must
+    agree with the B = 32 run to GEMM-kernel-choice rounding (the hand-written kernels are bitwise
+    batch-invariant, tests/test_gpu_parity_full.py); oracle parity inside such batches is
+    tests/test_gpu_shards.py."""
+    res = {}
+    img4, words4, out4 = head4
+    for B in (64, 128):
+        g = torch.Generator(device=device).manual_seed(SEED + B)
+        img = torch.randn((B, 3, 512, 512), device=device, generator=g)
+        words = torch.randint(0, 1000, (B, 20), device=device, generator=g)
+        img[:4], words[:4] = img4, words4
+        with torch.no_grad():
+            for _ in range(warmup + 1):
+                out = net(img, words)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                out = net(img, words)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+        ok = tuple(out.shape) == (B, 1, 512, 512) and bool(torch.isfinite(out).all())
+        rel = float((out[:4] - out4).abs().max() / out4.abs().max())
+        res["B=%d" % B] = {"gpus_in_configs2": 256 // B, "queries_per_s": round(B / dt, 2),
+                           "ms_per_step": round(dt * 1e3, 3), "steps": steps, "finite": ok,
+                           "rel_diff_vs_same_samples_in_B32": rel,
+                           "peak_mem_GB": round(torch.cuda.max_memory_allocated(device) / 1e9, 2)}
+        del img, words, out
+        torch.cuda.empty_cache()
+    return res
+
+
+def train320_child(steps=3, warmup=2, limit_s=420):
+    """configs[3] as `bench.py --workload train320 --steps 3 --warmup 2` in a child process (started,
+    not exec'ed) under a time limit; returns a summary of its JSON line."""
+    import subprocess
+    env = dict(os.environ, DMN_BENCH_WATCHDOG=os.environ.get("DMN_BENCH_WATCHDOG", "300,60"))
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "train320", "--steps", str(steps),
+           "--warmup", str(warmup)]
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=limit_s)
+    except subprocess.TimeoutExpired:
+        return {"error": "no result within %d s" % limit_s}
+    wall = time.perf_counter() - t0
+    rows = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not rows:
+        return {"error": "rc %d" % r.returncode, "stderr_tail": r.stderr.decode(errors="replace")[-600:]}
+    t = json.loads(rows[-1])
+    keep = ("value", "unit", "steps", "warmup", "ms_per_step", "loss", "hip_kernels_ms_per_step")
+    out = {"workload": t["config"]["workload"], "batch_per_gpu": t["config"]["batch_per_gpu"]}
+    out.update({k: t[k] for k in keep})
+    out["sru_bwd"] = {k: t["roofline"][k] for k in ("kernel", "avg_launch_ms", "achieved", "frac")}
+    out["hip_kernels"] = [{k: r_[k] for k in r_ if k in ("kernel", "calls", "avg_ms", "frac_of_8TBs",
+                                                          "achieved_TFLOPs", "bound", "frac_of_bound")}
+                          for r_ in t["hip_kernels"][:12]]
+    out["child_wall_s"] = round(wall, 1)
+    return out
 
 
 def run_msru_stress(device, steps, warmup, timer):
@@ -488,7 +606,9 @@ def main():
                     help="(image, query) pairs per GPU (default 32; 64 for train320)")
     ap.add_argument("--workload", default="dmn512", choices=["dmn512", "msru_stress", "train320"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-reps", type=int, default=15)
+    ap.add_argument("--cpu-reps", type=int, default=7)
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the objects measured after the timed region (shards, train320, serving_b1, msru_stress)")
     ap.add_argument("--no-head-link", action="store_true",
                     help="A/B switch: compact pyramid taps and the two-GEMM head levels instead of the "
                          "backbone writing each tap into the head's [x | feat] buffer")
@@ -498,10 +618,14 @@ def main():
     if args.batch is None:
         args.batch = 64 if args.workload == "train320" else 32
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus)                      # never returns; no GPU call has been made yet
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
@@ -528,7 +652,9 @@ def main():
             dist.barrier()
 
     if args.workload == "train320":
-        run_train320(args, device, rank, world, timer)
+        line = run_train320(args, device, rank, world, timer)
+        if rank == 0:
+            print(json.dumps(line))
         if world > 1:
             dist.destroy_process_group()
         return
@@ -590,6 +716,8 @@ def main():
             torch.cuda.synchronize()
             timer.enabled = False
     assert tuple(out.shape) == (B, 1, 512, 512) and bool(torch.isfinite(out).all())
+    head4 = (img[:4].clone(), words[:4].clone(), out[:4].clone())
+    proof = _world_proof(device, world)
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
     if world > 1:
@@ -609,7 +737,7 @@ def main():
     hip_ms = sum(r["total_ms"] for r in kernels) / table_steps
 
     line = {"metric": "queries/sec (whole node) high-res 512px DMN inference; mSRU achieved HBM GB/s",
-            "value": round(qps, 3), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+            "value": round(qps, 3), "unit": "queries/s", "n_gpus": proof["n_gpus"], "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
@@ -618,6 +746,7 @@ def main():
                                    "20-token queries, random init, eval()",
                        "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": "batch-sharded replicas, no collective"},
+            "collective_ranks": proof["collective_ranks"], "collective_backend": proof["collective_backend"],
             "roofline": roofline,
             "msru_GBs": dom["achieved_GBs"],
             "gemm_table_entries": gemm_table_entries,
@@ -640,11 +769,22 @@ def main():
         cb["gpu_vs_oracle_rel_err"] = float((gout - cout).abs().max() / cout.abs().max())
         cb["mask_agreement"] = float(((gout > 0) == (cout > 0)).float().mean())
         line["cpu_baseline"] = cb
+    if rank == 0 and world == 1 and not args.no_extras:
         line["serving_b1"] = serving_latency(net, device)
         # configs[4] microbench beside it (same process, after the timed region)
         row, ms = run_msru_stress(device, 20, 3, timer)
         line["msru_stress"] = {"workload": "T=4096 B=128 d=1000 k=3", "achieved_GBs": row["achieved_GBs"],
                                "frac_of_8TBs": row["frac_of_8TBs"], "avg_launch_ms": row["avg_ms"]}
+        # configs[2]'s 4-GPU and 2-GPU shards on this one GPU
+        try:
+            line["shards"] = run_shards(net, device, head4)
+        except Exception as e:                                        # the headline must survive
+            line["shards"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        # configs[3], bounded, in a fresh process of its own (this one's memory released first): a
+        # hang or crash there cannot take the headline with it
+        del net, img, out
+        torch.cuda.empty_cache()
+        line["train320"] = train320_child()
     if rank == 0:
         print(json.dumps(line))
     if world > 1:

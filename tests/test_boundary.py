@@ -193,3 +193,21 @@ def test_dmn_links_backbone_taps_to_head_levels():
     assert net.langvis.base.tap_prefix == {"conv5_3": 1005, "conv4_20": 512, "conv3_4": 256, "conv2_3": 128}
     low = dms_amd.DMN(50, num_filters=10, lang_layers=3, mix_we=True, pretrained=False, high_res=False)
     assert low.langvis.base.tap_prefix is None
+
+
+def test_bench_gpus_n_without_torchrun_refuses_a_box_with_fewer_devices():
+    """`python bench.py --gpus 2` (the driver's form: no torchrun environment) must start its ranks itself or
+    fail loudly -- never run one rank and print a line.  This container has no GPU: it must refuse, non-zero,
+    naming the device count, before any rank is started."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "DMN_BENCH_DEVICE")}
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer than 2 GPUs")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode != 0
+    assert b"GPU(s)" in r.stderr and b"refusing" in r.stderr
+    assert not [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]

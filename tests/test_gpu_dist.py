@@ -117,3 +117,29 @@ def test_device_buckets_through_rccl_in_place_one_rank_group(tmp_path):
         ref = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
         torch.testing.assert_close(g["grad"], ref, rtol=2e-5, atol=1e-6)
         assert g["calls"] == len(g["in_bwd"]) >= 3 and all(inb for _, inb in g["in_bwd"])
+
+
+@pytest.mark.timeout(420)
+def test_bench_gpus_2_starts_its_own_ranks_and_reports_what_the_collective_saw():
+    """`python bench.py --gpus 2` with no torchrun environment (the driver's form of the command): on this
+    one-GPU box it must refuse; with the rehearsal hooks (both ranks on card 0, gloo instead of RCCL, which
+    refuses two ranks on one device) the SAME launcher starts two ranks and the line's n_gpus /
+    collective_ranks come from the process group, not from the flag."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "DMN_BENCH_DEVICE")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--batch", "2", "--steps", "2",
+           "--warmup", "1", "--no-cpu-baseline", "--no-extras"]
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert r.returncode != 0 and b"refusing" in r.stderr
+    env.update(DMN_BENCH_DEVICE="0", DMN_BENCH_BACKEND="gloo")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=360)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-2000:]
+    rows = [json.loads(ln) for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(rows) == 1                                            # rank 0 prints ONE line
+    line = rows[0]
+    assert line["n_gpus"] == 2 and line["collective_ranks"] == 2 and line["collective_backend"] == "gloo"
+    assert line["config"]["global_batch"] == 4 and line["value"] > 0
