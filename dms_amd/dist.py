@@ -58,6 +58,15 @@ class OverlappedGradReducer(object):
       xGMI is point-to-point, so few large buckets beat many small ones).
     * ``finish()`` (after ``backward()``, before ``optimizer.step()``) launches what did not
       fill up (parameters without a gradient this step), waits for all of it and averages.
+    * Collectives go out strictly in bucket-index order on every rank (a bucket that fills up
+      early waits for the buckets in front of it), so ranks whose graphs produce gradients in a
+      different order -- or leave different parameters without one -- still issue matching
+      collectives.  Parameters that received no gradient in the FIRST step are taken to be unused
+      for good (their bucket no longer waits for them: it would otherwise hold back every bucket
+      behind it until ``finish()``); if one of them does get a gradient later, after its bucket has
+      gone out, that raises.  ONE ``backward()`` per ``finish()``: a gradient that arrives for a bucket
+      whose exchange is already in flight (a second backward, ``retain_graph`` replays,
+      gradient accumulation) raises instead of being reduced half-way.
 
     Use ``reducer.zero_grad()`` instead of ``optimizer.zero_grad(set_to_none=True)``, which would
     drop the views.  Without a process group (or world size 1) everything degrades to plain
@@ -97,12 +106,17 @@ class OverlappedGradReducer(object):
             self._expected.append(len(ps))
         self._arrived = [0] * len(self.buckets)
         self._work = [None] * len(self.buckets)
+        self._next = 0                                   # first bucket whose collective has not been issued
+        self._learned = False                            # _expected still counts every parameter of a bucket
         self._in_backward = True
         self.launch_log = []
         # backend gloo + buckets in device memory (the one-GPU rehearsal of the N > 1 path): the exchange
-        # is staged through pinned host memory by the reducer itself.  gloo's own device-tensor path
-        # hung on the MI355X box in the second training step -- both ranks inside wait() of the first
-        # bucket, same launch order on both (profiles/r2_train320_2rank_gloo.md) -- and host tensors are
+        # is staged through pinned host memory by the reducer itself.  ProcessGroupGloo's own device-tensor
+        # path does not return from its SECOND 128 MB all-reduce on this stack -- reproduced without this
+        # class, without hooks, from the main thread and even in a ONE-rank group (tools/gloo_hook_repro.py,
+        # profiles/r3_gloo_device_allreduce_repro.md: its two worker threads spin inside the HIP runtime;
+        # 1 MB tensors and the same stream / pinned-copy / worker-thread pattern in plain torch are fine) --
+        # so the cause is in that backend, not in how the collectives are issued here.  Host tensors are
         # what gloo reduces anyway.  RCCL ("nccl") reduces the device buckets in place.
         self._staged = (self._collective and self.buckets and self.buckets[0].is_cuda
                         and dist.get_backend(group) == "gloo")
@@ -137,9 +151,16 @@ class OverlappedGradReducer(object):
         if p.grad.data_ptr() < self.buckets[bi].data_ptr() or p.grad.numel() != p.numel():
             raise RuntimeError("OverlappedGradReducer: a .grad no longer views its bucket "
                                "(use reducer.zero_grad(), not zero_grad(set_to_none=True))")
+        if self._work[bi] is not None:
+            raise RuntimeError("OverlappedGradReducer: a gradient arrived for bucket %d after its exchange was "
+                               "launched -- one backward() per finish() (no gradient accumulation or "
+                               "retain_graph replays between them), and the set of parameters that receive "
+                               "a gradient must not grow after the first step" % bi)
         self._arrived[bi] += 1
-        if self._arrived[bi] == self._expected[bi]:
-            self._launch(bi)
+        # strictly in bucket order: a full bucket goes out once every bucket in front of it has
+        while self._next < len(self.buckets) and self._arrived[self._next] == self._expected[self._next]:
+            self._launch(self._next)
+            self._next += 1
 
     def zero_grad(self):
         for flat in self.buckets:
@@ -149,8 +170,9 @@ class OverlappedGradReducer(object):
         """Wait for every bucket (launching those that never filled up) and average.
         Returns the number of all-reduce calls of this step."""
         self._in_backward = False
-        for bi in range(len(self.buckets)):
+        for bi in range(self._next, len(self.buckets)):
             self._launch(bi)
+        self._next = len(self.buckets)
         if self._staged:
             works = []
             for bi, done in enumerate(self._work):
@@ -175,8 +197,13 @@ class OverlappedGradReducer(object):
                 if self.average and self.world > 1:
                     self.buckets[bi].div_(self.world)
         calls = len(self._work)
+        if not self._learned:
+            # static graph assumed from here on: what did not arrive in the first step is not waited for
+            self._expected = list(self._arrived)
+            self._learned = True
         self._arrived = [0] * len(self.buckets)
         self._work = [None] * len(self.buckets)
+        self._next = 0
         self._in_backward = True
         return calls
 

@@ -118,10 +118,35 @@ def test_overlapped_gradient_allreduce_world2_launches_from_hooks_and_equals_sin
         ref = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
         torch.testing.assert_close(got["grad"], ref, rtol=1e-5, atol=1e-6)
         assert got["calls"] == 3 and got["views"]
-        # buckets 1 and 2 fill up during backward in that order (reverse layer order); bucket 0 holds
-        # the unused parameter and is launched by finish()
-        assert got["log_bwd"] == [(1, True), (2, True)]
-        assert got["log"] == [(1, True), (2, True), (0, False)]
+        # collectives go out strictly in bucket order.  Step 0: bucket 0 holds the unused parameter, never
+        # fills up and holds the others back until finish().  From step 1 on the reducer knows that
+        # parameter receives no gradient: every bucket goes out during backward, last layers first.
+        if step == 0:
+            assert got["log_bwd"] == [] and got["log"] == [(0, False), (1, False), (2, False)]
+        else:
+            assert got["log_bwd"] == [(0, True), (1, True), (2, True)] and got["log"] == got["log_bwd"]
         # autograd's hook order: last layer's parameters first
         assert got["seen"][0] in (4, 5) and got["seen"][-1] in (0, 1) and 6 not in got["seen"]
         assert float(got["unused"].abs().sum()) == 0.0
+
+
+def test_second_backward_before_finish_raises_instead_of_reducing_half_way():
+    """A gradient that arrives for a bucket whose exchange is already in flight (second backward() before
+    finish(): gradient accumulation, retain_graph) would be accumulated into a bucket RCCL is reducing:
+    the reducer must raise.  After finish() the next step works again."""
+    model = _toy()
+    red = OverlappedGradReducer(list(model.parameters()), bucket_mb=25 * 4 / (1 << 20))
+    x = torch.arange(8 * 6, dtype=torch.float32).view(8, 6) / 10.0
+    red.zero_grad()
+    model(x).pow(2).mean().backward()
+    with pytest.raises(RuntimeError, match="one backward"):
+        model(x).pow(2).mean().backward()
+    red.finish()
+    red.zero_grad()
+    model(x).pow(2).mean().backward()
+    assert red.finish() == len(red.buckets)
+    ref = _toy()
+    ref(x).pow(2).mean().backward()
+    for p, q in zip(model.parameters(), ref.parameters()):
+        torch.testing.assert_close(p.grad, q.grad)
+    red.remove()
