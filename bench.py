@@ -53,7 +53,8 @@ SEED = 1111                    # reference default seed (train.py:75)
 
 
 # the mSRU entry points: timed with HIP events inside the timed region (the roofline kernel is one of them)
-MSRU_ENTRY_POINTS = frozenset(["dmn_sru_fwd", "dmn_sru_fwd_scan", "dmn_sru_state_fwd", "dmn_mix_sru_fwd"])
+MSRU_ENTRY_POINTS = frozenset(["dmn_sru_fwd", "dmn_sru_fwd_scan", "dmn_sru_state_fwd", "dmn_mix_sru_fwd",
+                               "dmn_sru_fwd_image"])
 
 
 class LaunchTimer(object):
@@ -92,6 +93,10 @@ class LaunchTimer(object):
             label = "sru_fwd k=%d T=%d cols=%d%s%s" % (
                 k, T, B * d, " tail" if h_t0 else "", " scan" if name.endswith("scan") else "")
             return label, rd + wr
+        if name == "dmn_sru_fwd_image":
+            T, B, d, k = args[7:11]
+            return ("sru_fwd k=%d T=%d cols=%d -> (B, d, H, W) image" % (k, T, B * d),
+                    (4 * k + (4 if k == 3 else 0) + 4) * T * B * d)
         if name == "dmn_sru_bwd":
             T, B, d, k = args[11:15]
             per = (4 * k + (4 if k == 3 else 0) + 8) + (4 * k + (4 if k == 3 else 0))
@@ -115,6 +120,9 @@ class LaunchTimer(object):
         if name == "dmn_mix_bcast_add":
             B, L, K, S, M = args[6:11]
             return "mix_bcast_add", 4 * B * (S * M + L * M + L * K * S + S * L * M)
+        if name == "dmn_bias_sigmoid":
+            rows, cols = args[2:4]
+            return "bias_sigmoid (filter bank)", 8 * rows * cols
         if name == "dmn_cat_coords":
             B, C, H, W = args[2:6]
             return "cat_coords", 4 * B * H * W * (2 * C + 8)

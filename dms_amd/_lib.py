@@ -22,12 +22,14 @@ SIGNATURES = {
     "dmn_sru_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p],
     "dmn_sru_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
     "dmn_sru_fwd_scan": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _p],
+    "dmn_sru_fwd_image": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _ll, _i, _p],
     "dmn_sru_fwd_scan_noalloc": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _p],
     "dmn_sru_state_fwd": [_p, _p, _p, _p, _i, _i, _i, _p],
     "dmn_sru_state_fwd_train": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
     "dmn_sru_state_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "dmn_sru_state_fwd_scan": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "dmn_sru_scan_workspace_floats": [_i, _i, _i, _i],
+    "dmn_bias_sigmoid": [_p, _p, _ll, _i, _p],
     "dmn_cat_coords": [_p, _p, _i, _i, _i, _i, _p],
     "dmn_dynfilter_fwd": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
     "dmn_dynfilter_fwd_ws": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],

@@ -2,6 +2,7 @@
 //
 //  dmn_cat_coords        : dmn.py:142 + 225-246   (coordinate channels written on device)
 //  dmn_cat_upsample2x    : dmn.py:324,337-338     (cat + nn.Upsample(x2, bilinear) in one pass)
+//  dmn_bias_sigmoid      : dmn.py:173-174         (the filter Linear's bias add + F.sigmoid, in place)
 //
 // All of these are pure HBM streaming: one 16-byte store per lane, inputs re-read from
 // L1/L2 (each input element feeds 4 outputs of the x2 upsample).
@@ -228,9 +229,48 @@ static int stream_grid(long long work_items)
     return (int)blocks;
 }
 
+// x[r, c] = sigmoid(x[r, c] + bias[c]) in place, 4 columns per lane (cols % 4 == 0) or 1.
+// One streaming pass: 8 B per element.  The GEMM in front of it runs bias-free (beta = 0).
+template <int VEC>
+__global__ void __launch_bounds__(256)
+bias_sigmoid_kernel(float *__restrict__ x, const float *__restrict__ bias, long long rows, int cols)
+{
+    const int cv = cols / VEC;
+    const int c = (blockIdx.x * blockDim.x + threadIdx.x);
+    if (c >= cv) return;
+    float b[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) b[e] = bias[c * VEC + e];
+    for (long long r = blockIdx.y; r < rows; r += gridDim.y) {
+        float *p = x + r * cols + (long long)c * VEC;
+        if (VEC == 4) {
+            const f32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(p));
+            *reinterpret_cast<float4 *>(p) = make_float4(sigmoid_f(v.x + b[0]), sigmoid_f(v.y + b[1]),
+                                                         sigmoid_f(v.z + b[2]), sigmoid_f(v.w + b[VEC - 1]));
+        } else {
+            *p = sigmoid_f(*p + b[0]);
+        }
+    }
+}
+
 }  // namespace dmn
 
 using namespace dmn;
+
+extern "C" int dmn_bias_sigmoid(float *x, const float *bias, long long rows, int cols, void *stream)
+{
+    if (!x || !bias) return fail(-1, "dmn_bias_sigmoid: NULL pointer");
+    if (rows < 0 || cols <= 0) return fail(-4, "dmn_bias_sigmoid: bad sizes rows=%lld cols=%d", rows, cols);
+    if (rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = (cols % 4 == 0) && !(((uintptr_t)x | (uintptr_t)bias) & 15);
+    const int cv = vec ? cols / 4 : cols;
+    const unsigned gy = (unsigned)(rows < 2048 ? rows : 2048);
+    dim3 grid((cv + 255) / 256, gy);
+    if (vec) hipLaunchKernelGGL(bias_sigmoid_kernel<4>, grid, dim3(256), 0, s, x, bias, rows, cols);
+    else     hipLaunchKernelGGL(bias_sigmoid_kernel<1>, grid, dim3(256), 0, s, x, bias, rows, cols);
+    return launch_status("dmn_bias_sigmoid");
+}
 
 extern "C" int dmn_cat_coords(const float *vis, float *V, int B, int C, int H, int W, void *stream)
 {

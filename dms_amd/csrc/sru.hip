@@ -32,6 +32,12 @@ void launch_sru_fwd_k4(int act, bool store_c, int depth, dim3 grid, hipStream_t 
                        const float *x, const float *bias, const float *c0, float *h, float *c_all,
                        float *c_last, int T, int ncols, int d, float scale_x, int h_t0,
                        int chunk_len, const float2 *carries, int blk0 = 0);
+void launch_sru_fwd_img_k3(int act, int depth, dim3 grid, hipStream_t s, const float *U, const float *x,
+                           const float *bias, const float *c0, float *out, float *c_last, int T, int ncols,
+                           int d, float scale_x, int h_t0, int chunk_len, const float2 *carries, long long out_bs);
+void launch_sru_fwd_img_k4(int act, int depth, dim3 grid, hipStream_t s, const float *U, const float *x,
+                           const float *bias, const float *c0, float *out, float *c_last, int T, int ncols,
+                           int d, float scale_x, int h_t0, int chunk_len, const float2 *carries, long long out_bs);
 void launch_sru_fwd_k2(int depth, dim3 grid, hipStream_t s, const float *U, const float *bias,
                        const float *c0, float *c_all, float *c_last, int T, int ncols, int d, int blk0 = 0);
 constexpr int WHOLE_SEQUENCE = 0x7fffffff / 2;   // chunk_len of the un-chunked scan
@@ -290,6 +296,55 @@ extern "C" int dmn_sru_fwd_scan(const float *U, const float *x, const float *bia
     if (!workspace || ((uintptr_t)workspace & 7)) return fail(-1, "dmn_sru_fwd_scan: workspace must be non-NULL, 8-byte aligned");
     return fwd_scan_impl("dmn_sru_fwd_scan", U, x, bias, c0, h, c_last, reinterpret_cast<float2 *>(workspace),
                          T, B, d, k, act, scale_x, h_t0, nchunks, (hipStream_t)stream);
+}
+
+
+// ------------------------------------------------------------------------------------
+// The scan with its hidden states stored as an image: out[b*out_bs + j*T + t] = h[t, b, j], i.e. the
+// (B, d, H, W) map of dmn.py:209-212 when the call scans the last H*W steps of the last mSRU layer -- no
+// (T, B, d) tensor, no permute / contiguous copy; out_bs lets the map be the first d channels of the head's
+// [x | feat] buffer (dmn.py:337).  nchunks > 1: the time-parallel variant for few columns (workspace as for
+// dmn_sru_fwd_scan); nchunks == 1: workspace may be NULL.
+// ------------------------------------------------------------------------------------
+extern "C" int dmn_sru_fwd_image(const float *U, const float *x, const float *bias, const float *c0,
+                                 float *out, float *c_last, float *workspace, int T, int B, int d, int k,
+                                 int act, float scale_x, long long out_bs, int nchunks, void *stream)
+{
+    const char *fn = "dmn_sru_fwd_image";
+    if (int rc = check_common(fn, U, x, bias, T, B, d, k, act)) return rc;
+    if (!out && T > 0) return fail(-1, "%s: out must not be NULL", fn);
+    if (out_bs < (long long)d * T) return fail(-4, "%s: out batch stride %lld < d*T = %lld", fn, out_bs, (long long)d * T);
+    if (nchunks < 1 || nchunks > 65535) return fail(-9, "%s: nchunks=%d outside [1, 65535]", fn, nchunks);
+    if (nchunks > 1 && (!workspace || ((uintptr_t)workspace & 7)))
+        return fail(-1, "%s: nchunks > 1 needs a non-NULL, 8-byte aligned workspace", fn);
+    const int ncols = B * d;
+    const int nwaves = (ncols + WAVE - 1) / WAVE;
+    hipStream_t s = (hipStream_t)stream;
+    if (T == 0) {                                               // nothing to scan: c_last = c0
+        if (c_last) {
+            hipError_t e = c0 ? hipMemcpyAsync(c_last, c0, sizeof(float) * ncols, hipMemcpyDeviceToDevice, s)
+                              : hipMemsetAsync(c_last, 0, sizeof(float) * ncols, s);
+            if (e != hipSuccess) return fail((int)e, "%s: %s", fn, hipGetErrorString(e));
+        }
+        return 0;
+    }
+    int chunk_len = WHOLE_SEQUENCE, used = 1;
+    const float2 *carries = nullptr;
+    if (nchunks > 1) {
+        chunk_len = (T + nchunks - 1) / nchunks;
+        used = (T + chunk_len - 1) / chunk_len;
+        float2 *cw = reinterpret_cast<float2 *>(workspace);
+        dim3 g(nwaves, used);
+        if (k == 3) hipLaunchKernelGGL((sru_chunk_aggregate<3, 8>), g, dim3(WAVE), 0, s, U, bias, cw, T, ncols, d, chunk_len);
+        else        hipLaunchKernelGGL((sru_chunk_aggregate<4, 8>), g, dim3(WAVE), 0, s, U, bias, cw, T, ncols, d, chunk_len);
+        carries = cw;
+    }
+    int depth = depth_override();
+    if (depth <= 0) depth = nchunks > 1 ? 8 : pick_depth(nwaves, true, k == 3 ? 2 : 1, 1);
+    dim3 grid(nwaves, used);
+    if (k == 3) launch_sru_fwd_img_k3(act, depth, grid, s, U, x, bias, c0, out, c_last, T, ncols, d, scale_x, 0, chunk_len, carries, out_bs);
+    else        launch_sru_fwd_img_k4(act, depth, grid, s, U, x, bias, c0, out, c_last, T, ncols, d, scale_x, 0, chunk_len, carries, out_bs);
+    return launch_status(fn);
 }
 
 // ------------------------------------------------------------------------------------

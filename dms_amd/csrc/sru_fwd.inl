@@ -80,6 +80,40 @@ __device__ __forceinline__ float4 slot_values(const Slot<2> &s) { return make_fl
 __device__ __forceinline__ float4 slot_values(const Slot<4> &s) { return make_float4(s.u.x, s.u.y, s.u.z, s.u.w); }
 __device__ __forceinline__ float4 slot_values(const Slot<3> &s) { return make_float4(s.u.x, s.u.y, s.u.z, s.x); }
 
+// h stored as an IMAGE (dmn.py:209-212: output[-(H*W):] -> permute(1, 2, 0) -> view(B, Hm, H, W)): column
+// (b, j) owns the row out[b*out_bs + j*T_img ..+ T_img) and time runs along it.  A lane per column would write
+// 4 bytes into 64 different rows per step; instead the wave parks 64 steps x 64 columns in LDS (rows padded to
+// 65 floats: both the per-step write and the transposed read are bank-conflict free) and writes them out as
+// 64 runs of 64 consecutive floats, lane l carrying time step l of the group.
+struct HtOut {
+    float *tile;             // LDS, 64 x 65 floats, this wave's
+    float *out;              // image base
+    unsigned row_lo, row_hi; // this lane's row start b*out_bs + j*T_img (elements), as two 32-bit halves for v_readlane
+    int t0;                  // image time index of local step 0 of the range being scanned
+    int ncols;               // valid columns of this wave (1 .. 64)
+};
+
+// write local steps [tl0, tl0 + cnt) of every valid column of the wave (cnt <= 64)
+__device__ __forceinline__ void ht_flush(const HtOut &ht, int tl0, int cnt)
+{
+    const int lane = threadIdx.x;
+    auto put = [&](int r, float v) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)ht.row_lo, r);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)ht.row_hi, r);
+        float *row = ht.out + (long long)(((unsigned long long)hi << 32) | lo);
+        if (lane < cnt) row[ht.t0 + tl0 + lane] = v;
+    };
+    int r = 0;
+    for (; r + 8 <= ht.ncols; r += 8) {                         // eight LDS reads in flight, then eight stores
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = ht.tile[lane * 65 + r + i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) put(r + i, v[i]);
+    }
+    for (; r < ht.ncols; ++r) put(r, ht.tile[lane * 65 + r]);
+}
+
 struct ScanPtrs {
     const char *ldU, *ldX;   // row of the first step of the range (loads)
     char *stH, *stC;         // row of the first step of the range (stores)
@@ -87,10 +121,10 @@ struct ScanPtrs {
 
 // n >= 1 steps starting at the rows in `p`; returns the carried cell state and leaves `p`
 // at row n.
-template <int K, int ACT, int DEPTH, bool STORE_C, bool STORE_H>
+template <int K, int ACT, int DEPTH, bool STORE_C, bool STORE_H, bool HT = false>
 __device__ __forceinline__ float scan_range(ScanPtrs &p, unsigned strideU, unsigned strideX,
                                             unsigned offU, unsigned offX, int n, float cur,
-                                            float bf2, float br2, float sx)
+                                            float bf2, float br2, float sx, const HtOut *ht = nullptr)
 {
     constexpr int NLD = (K == 3) ? 2 : 1;                       // VMEM loads per step
     // VMEM stores per step that a wait may leave outstanding: none (sru_ring.h, DMN_VMCNT_COUNT_STORES)
@@ -98,7 +132,8 @@ __device__ __forceinline__ float scan_range(ScanPtrs &p, unsigned strideU, unsig
     Slot<K> ring[DEPTH] = {};
     const ScanPtrs start = p;
 
-    auto step = [&](const float4 v, rsrc_t rH, rsrc_t rC, int i) {
+    // i: row inside the block (compile-time at every call site); tl: local step inside the range (HT only)
+    auto step = [&](const float4 v, rsrc_t rH, rsrc_t rC, int i, int tl) {
         // sigmoid(u + b) = 1 / (1 + 2^(-(u + b) log2 e)), bias pre-multiplied into b?2
         const float f = fast_rcp(1.0f + fast_exp2(__builtin_fmaf(v.y, -LOG2E, bf2)));
         const float r = fast_rcp(1.0f + fast_exp2(__builtin_fmaf(v.z, -LOG2E, br2)));
@@ -108,7 +143,12 @@ __device__ __forceinline__ float scan_range(ScanPtrs &p, unsigned strideU, unsig
         if (STORE_H) {
             const float xv = (K == 3) ? v.w * sx : v.w;
             const float hv = __builtin_fmaf(act_fwd<ACT>(cur) - xv, r, xv);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hv), rH, offX, i * strideX, DMN_ST_AUX);
+            if constexpr (HT) {
+                ht->tile[(tl & 63) * 65 + threadIdx.x] = hv;
+                if ((tl & 63) == 63) ht_flush(*ht, tl - 63, 64);        // wave-uniform branch
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hv), rH, offX, i * strideX, DMN_ST_AUX);
+            }
         }
     };
 
@@ -149,7 +189,7 @@ __device__ __forceinline__ float scan_range(ScanPtrs &p, unsigned strideU, unsig
             static_for<0, DEPTH>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 wait_slot<(DEPTH - 1 - i) * NLD + i * (NLD + NST)>(ring[i]);
-                step(slot_values(ring[i]), rH, rC, i);
+                step(slot_values(ring[i]), rH, rC, i, i);
                 load_clamped(ring[i], srdU, srdX, limU, limX, i);
             });
         }
@@ -163,7 +203,7 @@ __device__ __forceinline__ float scan_range(ScanPtrs &p, unsigned strideU, unsig
             static_for<0, DEPTH>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 wait_slot<(DEPTH - 1) * (NLD + NST)>(ring[i]);
-                step(slot_values(ring[i]), rH, rC, i);
+                step(slot_values(ring[i]), rH, rC, i, done + i);
                 issue_load(ring[i], srdU, srdX, offU, offX, (unsigned)i * strideU, (unsigned)i * strideX);
             });
         }
@@ -176,7 +216,7 @@ __device__ __forceinline__ float scan_range(ScanPtrs &p, unsigned strideU, unsig
             static_for<0, DEPTH>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 wait_slot<(DEPTH - 1) * (NLD + NST)>(ring[i]);
-                step(slot_values(ring[i]), rH, rC, i);
+                step(slot_values(ring[i]), rH, rC, i, done + i);
                 load_clamped(ring[i], srdU, srdX, limU, limX, i);
             });
         }
@@ -189,12 +229,14 @@ __device__ __forceinline__ float scan_range(ScanPtrs &p, unsigned strideU, unsig
         static_for<0, DEPTH>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             wait_slot<(DEPTH - 1 - i) * NLD>(ring[i]);
-            if (done + i < n) step(slot_values(ring[i]), rH, rC, i);
+            if (done + i < n) step(slot_values(ring[i]), rH, rC, i, done + i);
         });
     }
+    if constexpr (HT)
+        if (n & 63) ht_flush(*ht, n - (n & 63), n & 63);                // the last, partial group of steps
     p.ldU = start.ldU + (size_t)n * strideU;
     p.ldX = start.ldX + (size_t)n * strideX;
-    if (STORE_H) p.stH = start.stH + (size_t)n * strideX;
+    if (STORE_H && !HT) p.stH = start.stH + (size_t)n * strideX;
     if (STORE_C) p.stC = start.stC + (size_t)n * strideX;
     return cur;
 }
@@ -246,6 +288,75 @@ sru_fwd_cols(const float *__restrict__ U, const float *__restrict__ x,
     if (c_last && blockIdx.y == gridDim.y - 1) c_last[col] = cur;
 }
 
+
+// The same scan with h stored as an image (HtOut above): the last mSRU layer's tail, whose S hidden states ARE
+// the (B, Hm, H, W) map the head reads (dmn.py:209-212).  All 64 lanes stay alive (a lane past the last column
+// re-computes column ncols-1: in the write-out every lane carries a time step, not its own column).
+template <int K, int ACT, int DEPTH>
+__global__ void __launch_bounds__(WAVE)
+sru_fwd_cols_img(const float *__restrict__ U, const float *__restrict__ x,
+                 const float *__restrict__ bias, const float *__restrict__ c0,
+                 float *__restrict__ out, float *__restrict__ c_last,
+                 int T_total, int ncols, int d, float scale_x, int h_t0,
+                 int chunk_len, const float2 *__restrict__ carries, long long out_bs)
+{
+    __shared__ float tile[64 * 65];
+    const int col0 = (int)blockIdx.x * WAVE;
+    const int live = ncols - col0 < WAVE ? ncols - col0 : WAVE;          // >= 1 by the grid size
+    const int col = col0 + ((int)threadIdx.x < live ? (int)threadIdx.x : live - 1);
+    const int j = col % d;
+    const float bf2 = -LOG2E * bias[j], br2 = -LOG2E * bias[j + d];
+    float cur = c0 ? c0[col] : 0.0f;
+    const size_t nc = (size_t)ncols;
+    const int t_begin = blockIdx.y * chunk_len;
+    const int T = min(T_total, t_begin + chunk_len);
+    if (carries)
+        for (int cc = 0; cc < (int)blockIdx.y; ++cc) {
+            const float2 ab = carries[(size_t)cc * nc + col];
+            cur = __builtin_fmaf(ab.x, cur, ab.y);
+        }
+    if (T > t_begin) {
+        const unsigned strideU = (unsigned)(nc * K * sizeof(float)), strideX = (unsigned)(nc * sizeof(float));
+        const unsigned offU = (unsigned)col * K * sizeof(float), offX = (unsigned)col * sizeof(float);
+        ScanPtrs p;
+        p.ldU = reinterpret_cast<const char *>(U) + (size_t)t_begin * strideU;
+        p.ldX = reinterpret_cast<const char *>(x) + (size_t)t_begin * strideX;
+        p.stC = nullptr;
+        p.stH = nullptr;
+        const int t_mid = max(t_begin, min(h_t0, T));
+        if (t_mid > t_begin)
+            cur = scan_range<K, ACT, DEPTH, false, false>(p, strideU, strideX, offU, offX,
+                                                          t_mid - t_begin, cur, bf2, br2, scale_x);
+        if (T > t_mid) {
+            const unsigned long long row = (unsigned long long)((long long)(col / d) * out_bs
+                                                                + (long long)j * (T_total - h_t0));
+            HtOut ht;
+            ht.tile = tile;
+            ht.out = out;
+            ht.row_lo = (unsigned)(row & 0xffffffffull);
+            ht.row_hi = (unsigned)(row >> 32);
+            ht.t0 = t_mid - h_t0;
+            ht.ncols = live;
+            cur = scan_range<K, ACT, DEPTH, false, true, true>(p, strideU, strideX, offU, offX,
+                                                               T - t_mid, cur, bf2, br2, scale_x, &ht);
+        }
+    }
+    if (c_last && blockIdx.y == gridDim.y - 1 && (int)threadIdx.x < live) c_last[col] = cur;
+}
+
+template <int K, int ACT>
+static void launch_fwd_img(int depth, dim3 grid, hipStream_t s, const float *U, const float *x,
+                           const float *bias, const float *c0, float *out, float *c_last, int T, int ncols,
+                           int d, float scale_x, int h_t0, int chunk_len, const float2 *carries, long long out_bs)
+{
+    if (depth <= 8)
+        hipLaunchKernelGGL((sru_fwd_cols_img<K, ACT, 8>), grid, dim3(WAVE), 0, s, U, x, bias, c0, out, c_last,
+                           T, ncols, d, scale_x, h_t0, chunk_len, carries, out_bs);
+    else
+        hipLaunchKernelGGL((sru_fwd_cols_img<K, ACT, 16>), grid, dim3(WAVE), 0, s, U, x, bias, c0, out, c_last,
+                           T, ncols, d, scale_x, h_t0, chunk_len, carries, out_bs);
+}
+
 template <int K, int ACT, bool STORE_C>
 static void launch_fwd(int depth, dim3 grid, hipStream_t s, const float *U, const float *x,
                        const float *bias, const float *c0, float *h, float *c_all, float *c_last,
@@ -293,6 +404,18 @@ void DMN_SRU_LAUNCH_NAME(int depth, dim3 grid, hipStream_t s, const float *U, co
                                                c_last, T, ncols, d, 1.0f, T, 0x7fffffff / 2, nullptr, blk0);
 }
 #else
+void DMN_SRU_LAUNCH_IMG_NAME(int act, int depth, dim3 grid, hipStream_t s, const float *U, const float *x,
+                             const float *bias, const float *c0, float *out, float *c_last, int T, int ncols,
+                             int d, float scale_x, int h_t0, int chunk_len, const float2 *carries, long long out_bs)
+{
+    if (act == DMN_ACT_TANH)
+        launch_fwd_img<DMN_SRU_K, DMN_ACT_TANH>(depth, grid, s, U, x, bias, c0, out, c_last, T, ncols, d, scale_x, h_t0, chunk_len, carries, out_bs);
+    else if (act == DMN_ACT_RELU)
+        launch_fwd_img<DMN_SRU_K, DMN_ACT_RELU>(depth, grid, s, U, x, bias, c0, out, c_last, T, ncols, d, scale_x, h_t0, chunk_len, carries, out_bs);
+    else
+        launch_fwd_img<DMN_SRU_K, DMN_ACT_IDENTITY>(depth, grid, s, U, x, bias, c0, out, c_last, T, ncols, d, scale_x, h_t0, chunk_len, carries, out_bs);
+}
+
 void DMN_SRU_LAUNCH_NAME(int act, bool store_c, int depth, dim3 grid, hipStream_t s, const float *U,
                          const float *x, const float *bias, const float *c0, float *h,
                          float *c_all, float *c_last, int T, int ncols, int d, float scale_x,

@@ -97,6 +97,9 @@ class BaseDMN(nn.Module):
         # the gradients of comb_conv and of layer 0's weight arrive through it; layer 0's three
         # (S*L*B) x M x 4Hm GEMMs (forward, dgrad, wgrad) shrink to (S*B) x C x 4Hm ones
         self.fold_in_training = True
+        # inference: the last mSRU scan stores its kept hidden states as the (B, Hm, H, W) map itself
+        # (ops.sru_forward_image; dmn.py:209-212) instead of (S, B, Hm) + permute + contiguous
+        self.scan_writes_image = True
         self._fold_cache = None
         self.base = create_backbone(backend, pretrained=pretrained, extra=extra)
 
@@ -121,13 +124,29 @@ class BaseDMN(nn.Module):
                                              kernel_size=1)
 
     # -- the language-conditioned hot path, given backbone features -------------------
-    def hot_path(self, vis, lang):
+    def hot_path(self, vis, lang, image_dest=None):
         """vis (B, vis_size, H, W) backbone output, lang (B, L) int64 ->
-        (B, hid_mixed, H, W) if high_res else (B, 1, H, W)."""
+        (B, hid_mixed, H, W) if high_res else (B, 1, H, W).
+        image_dest (inference): a batch-strided (B, hid_mixed, H, W) view that the last mSRU scan
+        writes the map into (the first channels of the head's [x | feat] buffer); the returned
+        tensor is then that view."""
         with ops.gemm_backend():
-            return self._hot_path(vis, lang)
+            return self._hot_path(vis, lang, image_dest)
 
-    def _hot_path(self, vis, lang):
+    def _image_arg(self, T, S, B, H, W, image_dest, layer0_external):
+        """image_out argument of the mSRU call: None (the (S, B, Hm) form + permute), True (the scan
+        writes a fresh (B, Hm, S) map) or the caller's destination as (B, Hm, S).  dmn.py:209-212."""
+        if self.lstm or not self.scan_writes_image or not self.mrnn.can_image(T, S, layer0_external):
+            return None
+        if image_dest is not None:
+            Hm = self.mrnn.n_out
+            ok = (torch.is_tensor(image_dest) and image_dest.is_cuda and image_dest.dtype == torch.float32
+                  and tuple(image_dest.shape) == (B, Hm, H, W) and image_dest[0].is_contiguous())
+            if ok:
+                return image_dest.flatten(2)
+        return True
+
+    def _hot_path(self, vis, lang, image_dest=None):
         B, C, H, W = vis.shape
         S = H * W
         C8 = C + 8
@@ -135,18 +154,22 @@ class BaseDMN(nn.Module):
 
         V = ops.cat_coords(vis).view(B, C8, S)                    # dmn.py:138-142
 
-        we = self.emb(lang).transpose(0, 1).contiguous()          # (L, B, E)  dmn.py:147-149
+        we = self.emb(lang.t())                                   # (L, B, E)  dmn.py:147-149 (gathered in that order)
         L = we.shape[0]
         hl, _ = self.lang_model(we)                               # (L, B, Hd) dmn.py:156
         lang_cat = torch.cat([we, hl], dim=2).view(L * B, E + Hd)  # [WE, h]
         lin_in = lang_cat if self.mix_we else hl.reshape(L * B, Hd)  # dmn.py:163-167
 
-        filt = torch.addmm(self.adaptative_filter.bias, lin_in,
-                           self.adaptative_filter.weight.t()).sigmoid_()   # dmn.py:173-174
+        grad = torch.is_grad_enabled()
+        if grad:
+            filt = torch.addmm(self.adaptative_filter.bias, lin_in,
+                               self.adaptative_filter.weight.t()).sigmoid_()   # dmn.py:173-174
+        else:                                                      # bias-free GEMM, then bias + sigmoid in one pass
+            filt = ops.bias_sigmoid_(torch.mm(lin_in, self.adaptative_filter.weight.t()),
+                                     self.adaptative_filter.bias)
         filt = filt.view(L, B, K, C8)                              # dmn.py:176-177
         P = ops.dynfilter(V, filt)                                 # (L,B,K,S) dmn.py:178-184
 
-        grad = torch.is_grad_enabled()
         fold = (self.fold_comb_into_msru and not self.lstm and self.mrnn.rnn_lst[0].k == 4
                 and (not grad or (self.fold_in_training and K <= 10 and L <= 24)))
         if fold:
@@ -159,12 +182,16 @@ class BaseDMN(nn.Module):
             cell0 = self.mrnn.rnn_lst[0]
             if (not grad and self.fuse_mix_scan and K <= 16 and B * cell0.n_out >= MIX_SCAN_MIN_COLS):
                 # enough columns to occupy the SIMDs: the scan lanes build U0 themselves
+                img = self._image_arg(S * L, S, B, H, W, image_dest, True)
                 h0, c0_last = ops.mix_sru_fwd(A, Bt, P, Wp_f, cell0.bias, None, cell0.activation)
-                out, _ = self.mrnn(h0, tail=S, first_done=c0_last)
+                out, _ = self.mrnn(h0, tail=S, first_done=c0_last, image_out=img)
             else:
+                img = self._image_arg(S * L, S, B, H, W, image_dest, True) if not grad else None
                 U0 = ops.mix_bcast_add(A, Bt, P, Wp_f)              # (S*L, B, 4*Hm) = layer-0 U
-                out, _ = self.mrnn(U0, tail=S, projected=True)
-            out = out.permute(1, 2, 0).contiguous().view(B, -1, H, W)
+                out, _ = self.mrnn(U0, tail=S, projected=True, image_out=img)
+            if img is None:
+                out = out.permute(1, 2, 0).contiguous()             # dmn.py:210-212
+            out = out.view(B, -1, H, W)
             if not self.high_res:
                 oc = self.output_collapse                              # dmn.py:213-214
                 if grad:
@@ -183,9 +210,13 @@ class BaseDMN(nn.Module):
         if self.lstm:
             out, _ = self.mrnn(Q)
             out = out[-S:]
+            out = out.permute(1, 2, 0).contiguous()
         else:
-            out, _ = self.mrnn(Q, tail=S)                          # (S, B, Hm) dmn.py:204-209
-        out = out.permute(1, 2, 0).contiguous().view(B, -1, H, W)  # dmn.py:210-212
+            img = self._image_arg(S * L, S, B, H, W, image_dest, False) if not grad else None
+            out, _ = self.mrnn(Q, tail=S, image_out=img)           # (S, B, Hm) dmn.py:204-209
+            if img is None:
+                out = out.permute(1, 2, 0).contiguous()            # dmn.py:210-212
+        out = out.view(B, -1, H, W)
         if not self.high_res:
             out = self.output_collapse(out)                        # dmn.py:213-214
         return out
@@ -220,7 +251,17 @@ class BaseDMN(nn.Module):
 
     def forward(self, vis, lang):
         vis, base_features = self.base(vis)                        # dmn.py:134
-        return self.hot_path(vis, lang), base_features
+        # high-res inference: the backbone left room for the map in front of its last pyramid tap
+        # (DMN._link_head_buffers); the last mSRU scan writes it there, cat([x, feat]) costs nothing
+        dest = None
+        if self.high_res and not torch.is_grad_enabled() and base_features:
+            whole = getattr(base_features[-1], "_dmn_base", None)
+            Hm = self.mrnn.n_out if not self.lstm else -1
+            if (torch.is_tensor(whole) and whole.dim() == 4 and whole.is_contiguous()
+                    and whole.shape[1] == Hm + base_features[-1].shape[1]
+                    and tuple(whole.shape[2:]) == tuple(vis.shape[2:]) and whole.shape[0] == vis.shape[0]):
+                dest = whole[:, :Hm]
+        return self.hot_path(vis, lang, image_dest=dest), base_features
 
     def load_state_dict(self, new_state, strict=False):
         return _lenient_load(self, new_state)

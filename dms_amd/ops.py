@@ -215,6 +215,29 @@ def sru_forward_raw(u, x, bias, c0, act, scale_x, h_t0=0, want_c=False, nchunks=
     return h, c_all, c_last
 
 
+def sru_forward_image(u, x, bias, c0, act, scale_x, out=None, nchunks=None):
+    """The scan with h stored as an image (inference): u (T,B,d,k), x (T,B,d) or None -> out (B, d, T) with
+    out[b, j, t] = h[t, b, j] -- what dmn.py:209-212 builds with permute(1, 2, 0) -- and c_last (B, d).
+    `out` may be given: a batch-strided (B, d, T) view, e.g. the first d channels of the head's
+    [x | feat] buffer.  Bit-identical to sru_forward_raw(...)[0].permute(1, 2, 0)."""
+    T, B, d, k = u.shape
+    _chk("sru_fwd_image", u)
+    _chk("sru_fwd_image", x, (T, B, d) if x is not None else None)
+    _chk("sru_fwd_image", bias, (2 * d,))
+    _chk("sru_fwd_image", c0, (B, d) if c0 is not None else None)
+    with torch.cuda.device(u.device):
+        if out is None:
+            out = torch.empty((B, d, T), device=u.device, dtype=torch.float32)
+        bs = _chk_batch_strided("sru_fwd_image", out, (B, d, T))
+        c_last = torch.empty((B, d), device=u.device, dtype=torch.float32)
+        if nchunks is None:
+            nchunks = sru_scan_chunks(T, B * d)
+        ws = torch.empty(2 * nchunks * B * d, device=u.device, dtype=torch.float32) if nchunks > 1 else None
+        _lib.call("dmn_sru_fwd_image", _ptr(u), _ptr(x), _ptr(bias), _ptr(c0), _ptr(out), _ptr(c_last),
+                  _ptr(ws), T, B, d, k, ACT_IDS[act], float(scale_x), bs, int(nchunks), _stream())
+    return out, c_last
+
+
 def sru_state(u2, bias, c0=None, nchunks=None):
     """Cell state after the last step for u2 (T, B, d, 2) = [u0 | forget]; inference only.
     Few columns (small B): time is cut into chunks that run concurrently (sru_scan_chunks)."""
@@ -338,6 +361,17 @@ class _CatCoords(torch.autograd.Function):
 
 def cat_coords(vis):
     return _CatCoords.apply(vis.contiguous())
+
+
+def bias_sigmoid_(x, bias):
+    """x (rows, cols) <- sigmoid(x + bias[None, :]) in place (inference): the filter Linear's bias add and
+    F.sigmoid (dmn.py:173-174) as one streaming pass behind a bias-free GEMM."""
+    rows, cols = x.shape
+    _chk("bias_sigmoid", x)
+    _chk("bias_sigmoid", bias, (cols,))
+    with torch.cuda.device(x.device):
+        _lib.call("dmn_bias_sigmoid", _ptr(x), _ptr(bias), int(rows), int(cols), _stream())
+    return x
 
 
 # ------------------------------------------------------------------------------------

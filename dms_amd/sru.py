@@ -66,10 +66,12 @@ class SRUCell(nn.Module):
             self.__dict__["_w01"] = cached
         return cached[1]
 
-    def _forward_tail(self, x, c0, h_t0):
+    def _forward_tail(self, x, c0, h_t0, image_out=None):
         """Inference, hidden states wanted from step h_t0 on only: the earlier steps reach the
         output through the cell state alone, so they are projected onto the u0 / forget
-        columns (2 of k: a third less GEMM work for k = 3) and run through the state-only scan."""
+        columns (2 of k: a third less GEMM work for k = 3) and run through the state-only scan.
+        image_out: True or a (B, n_out, T - h_t0) batch-strided view -> the hidden states come back
+        as that image, (B, n_out, T - h_t0), instead of (T - h_t0, B, n_out)."""
         T, B, n_in = x.shape
         head = x[:h_t0].reshape(h_t0 * B, n_in)
         u2 = ops.tuned_matmul(head, self._state_weight()).view(h_t0, B, self.n_out, 2)
@@ -77,10 +79,13 @@ class SRUCell(nn.Module):
         tail = x[h_t0:]
         u = ops.tuned_matmul(tail.reshape((T - h_t0) * B, n_in), self.weight).view(
             T - h_t0, B, self.n_out, self.k)
+        if image_out is not None:
+            return ops.sru_forward_image(u, tail if self.k == 3 else None, self.bias, c_mid, self.activation,
+                                         self.scale_x, out=None if image_out is True else image_out)
         return ops.sru_compute(u, tail if self.k == 3 else None, self.bias, c_mid,
                                self.activation, self.scale_x, 0)
 
-    def forward(self, input, c0=None, h_t0=0):
+    def forward(self, input, c0=None, h_t0=0, image_out=None):
         if input.dim() != 3:
             raise ValueError("SRUCell expects (len, batch, n_in), got %s" % (tuple(input.shape),))
         T, B, n_in = input.shape
@@ -90,8 +95,10 @@ class SRUCell(nn.Module):
         needs_grad = torch.is_grad_enabled() and (
             x.requires_grad or self.weight.requires_grad or self.bias.requires_grad
             or (c0 is not None and c0.requires_grad))
+        if image_out is not None and (needs_grad or not (0 < h_t0 < T and self.state_only_head)):
+            raise RuntimeError("SRUCell: image_out needs inference mode, 0 < h_t0 < T and state_only_head")
         if 0 < h_t0 < T and not needs_grad and self.state_only_head:
-            return self._forward_tail(x, c0, h_t0)
+            return self._forward_tail(x, c0, h_t0, image_out)
         if needs_grad and 0 < h_t0 < T and self.state_only_head_in_training:
             # training, hidden states wanted from step h_t0 on only: the earlier steps reach the loss
             # through the cell state alone, so they -- and their dgrad / wgrad GEMMs -- run on the
@@ -129,13 +136,26 @@ class SRU(nn.Module):
         for cell in self.rnn_lst:
             cell.set_bias(bias_val)
 
-    def forward(self, input, c0=None, return_hidden=True, tail=None, projected=False, first_done=None):
+    def can_image(self, T, tail, layer0_external=False):
+        """Whether forward(..., tail=tail, image_out=...) is available: inference, a last layer that is not
+        a layer 0 run or projected by the caller, a real head (0 < T - tail) and the state-only head enabled."""
+        if torch.is_grad_enabled() or tail is None or not (0 < T - int(tail) < T):
+            return False
+        if self.depth == 1 and layer0_external:
+            return False
+        return bool(self.rnn_lst[-1].state_only_head)
+
+    def forward(self, input, c0=None, return_hidden=True, tail=None, projected=False, first_done=None,
+                image_out=None):
         """``tail=n`` (extension): only the last n steps of the LAST layer's h are produced
         (what dmn.py:209 keeps), so the final scan stores S instead of S*L rows.
         ``projected=True`` (extension): ``input`` is already layer 0's U = x.W,
         shape (len, B, hidden*4); layer 0 must be a k = 4 cell.
         ``first_done=c_last`` (extension): ``input`` is already layer 0's hidden sequence (the
-        caller ran layer 0 itself, e.g. ops.mix_sru_fwd) and c_last its final cell state."""
+        caller ran layer 0 itself, e.g. ops.mix_sru_fwd) and c_last its final cell state.
+        ``image_out`` (extension, inference, with ``tail``): True or a (B, hidden, tail) batch-strided
+        view -> the last layer's kept hidden states come back as that image -- what dmn.py:210-212
+        builds with permute(1, 2, 0) -- written by the scan itself; see can_image()."""
         if input.dim() != 3:
             raise ValueError("SRU expects (len, batch, n_in), got %s" % (tuple(input.shape),))
         T = input.shape[0]
@@ -150,6 +170,8 @@ class SRU(nn.Module):
                     prev = prev[h_t0:]
             elif i == 0 and projected:
                 prev, c = cell.forward_projected(prev, c0s[i], h_t0)
+            elif last and image_out is not None:
+                prev, c = cell(prev, c0s[i], h_t0, image_out=image_out)
             else:
                 prev, c = cell(prev, c0s[i], h_t0)
             lst.append(c)

@@ -67,6 +67,22 @@ int dmn_sru_fwd_scan(const float *U, const float *x, const float *bias, const fl
                      int nchunks, void *stream);
 
 /*
+ * The scan of the LAST mSRU layer's tail with its hidden states stored as the image the reference
+ * builds from them: dmn.py:209-212 `output[-(H*W):]` -> `permute(1, 2, 0)` -> `view(B, Hm, H, W)`.
+ * Same inputs and arithmetic as dmn_sru_fwd over T = H*W steps (the caller passes the tail's U / x and
+ * the cell state after the steps before it as c0); instead of h (T,B,d) it writes
+ *     out[b*out_bs + j*T + t] = h[t, b, j]
+ * so that `out` IS the (B, d, H, W) map -- out_bs (in floats, >= d*T) lets it be the first d channels
+ * of the head's cat([x, feat], 1) buffer (dmn.py:337).  The wave transposes 64 steps x 64 columns
+ * through LDS and writes runs of 64 consecutive floats.  Bit-identical to dmn_sru_fwd + permute.
+ *   nchunks > 1: time-parallel variant for few columns, `workspace` as for dmn_sru_fwd_scan;
+ *   nchunks == 1: one pass, workspace may be NULL.
+ */
+int dmn_sru_fwd_image(const float *U, const float *x, const float *bias, const float *c0,
+                      float *out, float *c_last, float *workspace, int T, int B, int d, int k,
+                      int act, float scale_x, long long out_bs, int nchunks, void *stream);
+
+/*
  * dmn_sru_fwd_scan WITHOUT a caller workspace, for callers that cannot allocate device memory
  * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has
  * no counterpart in the reference.  Same arguments, kernels and results (bit for bit) as
@@ -131,6 +147,16 @@ int dmn_sru_bwd(const float *U, const float *x, const float *bias, const float *
                 const float *c_all, const float *grad_h, const float *grad_last,
                 float *grad_U, float *grad_x, float *grad_bias, float *grad_c0,
                 int T, int B, int d, int k, int act, float scale_x, void *stream);
+
+/*
+ * Bias add + sigmoid of the adaptive filter bank, in place: dmn.py:173-174
+ * `filters = self.adaptative_filter(linear_in)` + `F.sigmoid(filters)`.  The Linear's GEMM runs
+ * bias-free in front of it (library GEMM, beta = 0); this one streaming pass (8 B per element)
+ * replaces the bias broadcast, the GEMM's read of it and the separate sigmoid pass.
+ *   x (rows, cols) row-major, contiguous: x[r, c] = 1 / (1 + exp(-(x[r, c] + bias[c]))).
+ * Inference only (under autograd the torch Linear + sigmoid keep the graph).
+ */
+int dmn_bias_sigmoid(float *x, const float *bias, long long rows, int cols, void *stream);
 
 /*
  * Coordinate channels + concat.  Replaces BaseDMN.generate_spatial_batch

@@ -433,3 +433,65 @@ def test_config4_training_scans_T2000_B64_d1005_forward_with_c_and_backward_colu
     want_b = gb_r[:, 0, 9:].sum(axis=1)
     got_b = torch.stack([bg.grad[17], bg.grad[d + 17]]).cpu().numpy()
     np.testing.assert_allclose(got_b, want_b, rtol=5e-4, atol=1e-3)
+
+
+# ------------------------------------------------------------------------------------
+# a11: the last scan stores its hidden states as the (B, Hm, H, W) map itself (dmn.py:209-212)
+# ------------------------------------------------------------------------------------
+@pytest.mark.parametrize("T,B,d,k,nchunks,strided", [
+    (256, 32, 1005, 3, 1, True),      # the benchmarked tail: 503 waves, into the head's [x | feat] buffer
+    (100, 64, 1005, 3, 1, False),     # 320 px: T not a multiple of the 64-step groups
+    (256, 1, 1005, 3, 4, True),       # batch-1 serving: time-parallel variant
+    (70, 3, 37, 4, 1, False),         # k = 4, waves straddling samples, ragged last wave
+    (5, 2, 16, 3, 1, False),          # shorter than a group and than the ring
+    (64, 1, 64, 3, 1, False), (65, 1, 63, 4, 2, True), (1, 1, 1, 3, 1, False), (130, 2, 130, 3, 3, False)])
+@pytest.mark.parametrize("act", ["tanh", "relu"])
+def test_sru_forward_image_is_bit_identical_to_scan_then_permute(T, B, d, k, nchunks, strided, act):
+    u = det_uniform((T, B, d, k), 801, 1.5).to(DEV)
+    x = det_uniform((T, B, d), 802, 1.0).to(DEV) if k == 3 else None
+    bias = det_uniform((2 * d,), 803, 0.5).to(DEV)
+    c0 = det_uniform((B, d), 804, 1.0).to(DEV)
+    h, _, cl = ops.sru_forward_raw(u, x, bias, c0, act, 1.0, nchunks=nchunks)     # same chunking: same bits
+    want = h.permute(1, 2, 0).contiguous()
+    if strided:
+        whole = torch.full((B, d + 7, T), -123.0, device=DEV)
+        out, cl2 = ops.sru_forward_image(u, x, bias, c0, act, 1.0, out=whole[:, :d], nchunks=nchunks)
+        assert out.data_ptr() == whole.data_ptr()
+        assert bool((whole[:, d:] == -123.0).all())                  # nothing written past the map
+    else:
+        out, cl2 = ops.sru_forward_image(u, x, bias, c0, act, 1.0, nchunks=nchunks)
+    assert out.shape == (B, d, T)
+    assert torch.equal(out, want) and torch.equal(cl2, cl)
+
+
+def test_hot_path_with_and_without_the_image_store_gives_the_same_bits_and_fills_the_head_buffer():
+    """BaseDMN.hot_path (inference): scan_writes_image on / off must agree bit for bit (same kernels, same
+    arithmetic, only the store differs), and with a destination the map must land in it."""
+    cfg = dict(emb_size=32, hid_size=32, vis_size=64, num_filters=10, mixed_size=32, hid_mixed_size=37,
+               lang_layers=2, mixed_layers=3, mix_we=True, high_res=True)
+    net = dms_amd.BaseDMN(60, pretrained=False, **cfg)
+    net.base = torch.nn.Identity()
+    torch.nn.Module.load_state_dict(net, det_fill_state(net.state_dict()))
+    net = net.to(DEV).eval()
+    B, H, W, L = 3, 5, 4, 20
+    vis = det_uniform((B, 64, H, W), 811, 1.0).clamp_(min=0).to(DEV)
+    lang = det_ints((B, L), 812, 60).to(DEV)
+    with torch.no_grad():
+        net.scan_writes_image = False
+        ref = net.hot_path(vis, lang)
+        net.scan_writes_image = True
+        got = net.hot_path(vis, lang)
+        whole = torch.zeros((B, 37 + 11, H, W), device=DEV)
+        got2 = net.hot_path(vis, lang, image_dest=whole[:, :37])
+    assert ref.shape == (B, 37, H, W) and torch.equal(got, ref) and torch.equal(got2, ref)
+    assert got2.data_ptr() == whole.data_ptr() and torch.equal(whole[:, :37], ref) and float(whole[:, 37:].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("rows,cols", [(640, 26960), (3, 7), (1, 4), (2050, 12), (20, 2696 * 10)])
+def test_bias_sigmoid_in_place_matches_float64_linear_bias_plus_sigmoid(rows, cols):
+    """dmn.py:173-174 (the Linear's bias add + F.sigmoid) as one in-place pass: vs float64."""
+    x = det_uniform((rows, cols), 821, 6.0)
+    b = det_uniform((cols,), 822, 1.0)
+    got = ops.bias_sigmoid_(x.clone().to(DEV), b.to(DEV)).cpu()
+    want = torch.sigmoid(x.double() + b.double())
+    assert float((got.double() - want).abs().max()) < 3e-7       # sigmoid values are O(1): ~2 ulp
