@@ -105,8 +105,9 @@ class LaunchTimer(object):
             B, L, K, C, S = args[5:10]
             return "dynfilter_bwd", 4 * B * (2 * C * S + 2 * L * K * C + 2 * L * K * S)
         if name == "dmn_mix_bcast_add_bwd":
-            B, L, K, S, M = args[8:13]
-            return "mix_bcast_add_bwd", 4 * B * (2 * S * L * M + S * M + L * M + 2 * L * K * S + L * M * K)
+            # algorithmic: gQ read ONCE, gA / gBt / gP written, P read, gWp written once per sample
+            B, L, K, S, M = args[9:14]
+            return "mix_bcast_add_bwd", 4 * B * (S * L * M + S * M + L * M + 2 * L * K * S + M * K)
         if name == "dmn_cat_upsample2x_bwd":
             B, Cx, Cf, H, W = args[3:8]
             return "cat_upsample2x_bwd %dx%d" % (H, W), 4 * B * (Cx + Cf) * H * W * 5

@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DMN_HIP_LIB", os.path.join(_HERE, "lib", "libdmn_hip.so"))
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _p = ctypes.c_void_p
 _i = ctypes.c_int
@@ -37,7 +37,9 @@ SIGNATURES = {
     "dmn_dynfilter_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "dmn_mix_bcast_add": [_p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p],
     "dmn_mix_sru_fwd": [_p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
-    "dmn_mix_bcast_add_bwd": [_p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "dmn_mix_bcast_add_bwd": [_p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "dmn_mix_bwd_parts": [_i, _i, _i, _i, _i],
+    "dmn_mix_bwd_workspace_floats": [_i, _i, _i, _i, _i],
     "dmn_cat_upsample2x": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
     "dmn_cat_upsample2x_bwd": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
     "dmn_wino_cat_upsample2x_transform": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
@@ -54,6 +56,9 @@ SIGNATURES = {
     "dmn_dpn_stage_pass": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _ll, _p],
     "dmn_dpn_merge": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
 }
+
+# entry points whose return VALUE is not a C int
+RESTYPES = {"dmn_mix_bwd_workspace_floats": _ll}
 
 _lib = None
 
@@ -81,7 +86,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing: loud
         fn.argtypes = argtypes
-        fn.restype = _i
+        fn.restype = RESTYPES.get(name, _i)
     _lib = lib
     return lib
 

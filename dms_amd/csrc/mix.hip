@@ -10,6 +10,7 @@
 // Pure HBM write stream (Q = 20.5 MB/sample); A/Bt/P/Wp are re-read from L2.  One lane
 // owns 4 adjacent m (one 16-byte store per (s,t)); a wave writes 1 KiB contiguous.
 #include "common.h"
+#include "sru_ring.h"
 
 namespace dmn {
 
@@ -451,6 +452,311 @@ mix_bwd_word2_kernel(const float *__restrict__ gQ, const float *__restrict__ P,
             if (k < K) gWp_part[(((long long)t * B + b) * M + m + e) * K + k] = gw[e][k];
 }
 
+
+// ---- backward, ONE pass over gQ (round 3) ------------------------------------------------------------------
+// The two kernels above each stream gQ once (pixel pass: gA, gP; word pass: gBt, gWp): 2 x 2.06 GB at the
+// training step's folded width (B = 64, S = 100, M = 4020), 0.65 + 0.62 ms.  Here a 512-thread workgroup owns
+// 512 columns of ONE sample and walks ALL its pixels, so every output of those columns is formed from a single
+// read of gQ:  wave (wq, half) = words wq, wq+4, .. x columns half*256 + 4*lane .. +3; per lane
+//   w2  [4][5]  its columns' K <= 10 filter weights (pairs)            gA  summed over the wave's words per pixel,
+//   gbt [NW][4] gBt of its words, summed over pixels in pixel order         combined over the 4 word groups in LDS
+//   gw2 [4][5]  sum over its words and all pixels of gQ * P            v   partial dot products of a pixel
+// all FMAs packed over filter pairs (v_pk_fma_f32, the gQ value broadcast by op_sel).  A pixel's NW*10 partial
+// dot products are reduced over the 64 lanes in two batches of <= 32 by a transposing butterfly whose exchanges
+// are v_permlane32_swap / v_permlane16_swap (one swap + one add per pair: the swap IS the select) and DPP-fused
+// adds (row_ror:8, row_half_mirror, quad_perm) -- ~140 instructions per pixel and wave instead of ~250 with
+// __shfl_xor.  gP needs the sum over ALL column blocks: every block writes its share to `gPpart[cb]` and
+// mix_bwd_sum_parts adds them in block order (deterministic; no atomics).  gWp leaves as one (M, K) slab per
+// (sample, word group), summed by the caller.  One barrier per pixel (LDS scratch double-buffered).
+//
+// Loads.  With the rows of the NEXT pixel prefetched into registers the kernel ran 0.63 ms, 0.38 ms with the
+// loads removed (profiles/r3_mix_bwd_one.txt): two waves per SIMD x one pixel (5 KB) per wave in flight cannot
+// cover HBM latency at this rate, and there are no registers for a second pixel.  So the rows go global -> LDS
+// directly (buffer_load_dwordx4 .. lds, no VGPR destination), TWO pixels ahead, into a wave-private ring of
+// three pixel slots, and a pixel's filter responses P the same way, three pixels ahead into a ring of four.
+// These loads are inline asm that hipcc does not count; every wave issues exactly NW + 1 of them per pixel
+// (rows of words past L go to a dummy slot, their real slots stay zero) and retires them with ONE counted
+// s_waitcnt vmcnt(2*NW + 1) per pixel: that leaves the row loads of pixels s+1, s+2 and the P load of pixel
+// s+3 in flight and guarantees this pixel's rows and pixel s+2's P (older than all of those; loads retire in
+// order, and stores in between can only make the wait stricter).  A wave reads only its own row slots, so the
+// wait alone orders them (MI355X_MICROARCH.md item 7); P is read by every wave, two barriers after its wait.
+// Requires K <= 10, L <= 20, M % 4 == 0, 16-byte aligned gQ / gA / gBt.
+constexpr int MIX_ONE_COLS = 512;
+constexpr int MIX_ONE_NW = 5;            // words per wave: L <= 20
+constexpr int MIX_ONE_RUN = 16;          // pixels of gP gathered in LDS before they are written (64-byte runs)
+#ifndef DMN_MIX_ONE_PROBE
+#define DMN_MIX_ONE_PROBE 0      // timing probes (tools/probe_mix_one.sh): 1 no butterfly, 2 no combine/stores, 3 no gw FMAs, 4 no gQ loads
+#endif
+
+struct MixOneLds {
+    float G[3][8][MIX_ONE_NW][256];      // [pixel slot][wave][word][64 lanes x 4 columns]            120 KB
+    float dummy[256];                    // landing zone of loads nobody reads (words past L, waves 4-7's P piece)  1 KB
+    float Ps[4][256];                    // P[t, b, k, s] of a pixel as [t][k] (first 200 used)           4 KB
+    float ga[2][4][MIX_ONE_COLS];        //                                                              16 KB
+    float red[2][4][2][64];              //                                                               4 KB
+    float gp[4 * MIX_ONE_NW * MIX_BWD2_K][MIX_ONE_RUN];   // a run of pixels of this block's gP share  12.5 KB
+};
+
+__device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(unsigned long long)p; }
+
+// one 16-byte-per-lane (or 4-byte-per-lane) load straight into LDS at `lds_base + 16 (4) * lane`; not waited for
+__device__ __forceinline__ void dma_b128(unsigned lds_base, i32x4 srd, unsigned voff, unsigned soff)
+{
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds"
+                 :: "s"(lds_base), "v"(voff), "s"(srd), "s"(soff) : "memory", "m0");
+}
+__device__ __forceinline__ void dma_b32(unsigned lds_base, i32x4 srd, unsigned voff, unsigned soff)
+{
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+                 :: "s"(lds_base), "v"(voff), "s"(srd), "s"(soff) : "memory", "m0");
+}
+
+__global__ void __launch_bounds__(512)
+mix_bwd_one_kernel(const float *__restrict__ gQ, const float *__restrict__ P, const float *__restrict__ Wp, int ldw,
+                   float *__restrict__ gA, float *__restrict__ gBt, float *__restrict__ gPpart,
+                   float *__restrict__ gWpart, int B, int L, int K, int S, int M)
+{
+    constexpr int NW = MIX_ONE_NW, KR = MIX_BWD2_K, KP = KR / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    MixOneLds &sm = *reinterpret_cast<MixOneLds *>(lds_raw);
+    const int cb = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform for the compiler too (SGPR asm operands)
+    const int wq = wave & 3, half = wave >> 2;
+    const int m = cb * MIX_ONE_COLS + half * 256 + lane * 4;
+    const bool mok = m < M;                                // M % 4 == 0: all four columns or none
+
+    f32x2_t w2[4][KP], gw2[4][KP];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float *wr = Wp + (long long)(mok ? m + e : 0) * ldw;          // (in bounds either way)
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp) {
+            const float w0 = wr[2 * kp < K ? 2 * kp : 0], w1 = wr[2 * kp + 1 < K ? 2 * kp + 1 : 0];
+            w2[e][kp].x = (mok && 2 * kp < K) ? w0 : 0.0f;
+            w2[e][kp].y = (mok && 2 * kp + 1 < K) ? w1 : 0.0f;
+            gw2[e][kp] = (f32x2_t){0.0f, 0.0f};
+        }
+    }
+    f32x2_t gbt2[NW][2];
+#pragma unroll
+    for (int tt = 0; tt < NW; ++tt) gbt2[tt][0] = gbt2[tt][1] = (f32x2_t){0.0f, 0.0f};
+
+    // zero the row slots once: the slots of words past L are never written again (their loads land in `dummy`)
+    for (int i = tid; i < 3 * 8 * NW * 256 / 4; i += 512)
+        reinterpret_cast<float4 *>(&sm.G[0][0][0][0])[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    __syncthreads();
+
+    // P: lane (wave w, lane l) fetches value idx = 64*w + l = t*KR + k of a pixel (idx past the 4*NW*KR values,
+    // or a (t, k) outside L x K: any valid address; those values only ever multiply zero rows or feed outputs
+    // that are not stored)
+    const int pidx = tid < 4 * NW * KR ? tid : 0;          // (4 * NW * KR = 200 <= 256: waves 0 - 3)
+    const int pt = pidx / KR, pk = pidx - pt * KR;
+    const unsigned p_voff = (unsigned)(lbk_off(pt < L ? pt : L - 1, b, pk < K ? pk : K - 1, B, K, S) * sizeof(float));
+    const i32x4 p_srd = make_srd(P);                       // (L*B*K*S floats: far below the 2 GiB window)
+    auto dma_P = [&](int s) {                              // pixel s -> Ps[s & 3]
+        dma_b32(wave < 4 ? lds_addr(&sm.Ps[s & 3][wave * 64]) : lds_addr(&sm.dummy[0]), p_srd, p_voff,
+                (unsigned)((s < S ? s : S - 1) * sizeof(float)));
+    };
+    // gQ rows: descriptor re-based per pixel (wave-uniform), the words of a pixel as SGPR offsets, one constant
+    // VGPR byte offset per lane (a lane without a column re-reads the last valid one: its weights are zero)
+    const long long wordstride = (long long)B * M;          // floats between consecutive words of a pixel
+    const int mc = mok ? m : M - 4;
+    const unsigned lane_off = (unsigned)((((long long)wq * B + b) * M + mc) * sizeof(float));
+    auto dma_rows = [&](int s) {                           // pixel s -> G[s % 3][wave]
+        const i32x4 srd = make_srd(gQ + (long long)(s < S ? s : S - 1) * L * wordstride);
+        const int slot = s % 3;
+#pragma unroll
+        for (int tt = 0; tt < NW; ++tt) {
+            const bool real = wq + 4 * tt < L;             // wave-uniform
+            const unsigned dst = real ? lds_addr(&sm.G[slot][wave][tt][0]) : lds_addr(&sm.dummy[0]);
+#if DMN_MIX_ONE_PROBE != 4
+            dma_b128(dst, srd, lane_off, (unsigned)((real ? 4 * tt : 0) * wordstride * sizeof(float)));
+#endif
+        }
+    };
+    // prologue: P of pixels 0, 1, 2 and the rows of pixels 0, 1, in the loop's issue order (P first)
+    dma_P(0); dma_rows(0);
+    dma_P(1); dma_rows(1);
+    dma_P(2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // 32-slot transposing butterfly over the 64 lanes: afterwards lane l holds the wave total of value l >> 1
+    auto butterfly32 = [&](float (&v)[32]) -> float {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[j]), __float_as_uint(v[j + 16]), false, false);
+            v[j] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[j]), __float_as_uint(v[j + 8]), false, false);
+            v[j] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        }
+        auto dpp_step = [&](auto ctrl, int o, bool up) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j < o) {
+                    const float a = v[j], c = v[j + o];
+                    const float s1 = a + __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(a), decltype(ctrl)::value, 0xf, 0xf, false));
+                    const float s2 = c + __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(c), decltype(ctrl)::value, 0xf, 0xf, false));
+                    v[j] = up ? s2 : s1;
+                }
+            }
+        };
+        dpp_step(IC<0x128>{}, 4, (lane & 8) != 0);         // row_ror:8           lane i <-> i ^ 8
+        dpp_step(IC<0x141>{}, 2, (lane & 4) != 0);         // row_half_mirror     lane i <-> 7 - i (within 8)
+        dpp_step(IC<0x4e>{}, 1, (lane & 2) != 0);          // quad_perm [2,3,0,1] lane i <-> i ^ 2
+        return v[0] + __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v[0]), 0xb1, 0xf, 0xf, false));   // i <-> i ^ 1
+    };
+    constexpr int NB1 = 3, NB2 = NW - 3;                   // words per butterfly batch (30 + 20 values)
+
+    for (int s = 0; s < S; ++s) {
+        const int buf = s & 1;
+        // issue: P of pixel s+3, rows of pixel s+2 (past the end: the last pixel again, unused); then retire
+        // everything but those, the previous pixel's row loads and (older than them) nothing else
+        dma_P(s + 3);
+        dma_rows(s + 2);
+#if DMN_MIX_ONE_PROBE != 4
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NW + 1) : "memory");
+#else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        const float *Gw = &sm.G[s % 3][wave][0][lane * 4];
+        const float *Pw = &sm.Ps[s & 3][wq * KR];
+        f32x2_t ga2[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
+        float tot[2];
+#pragma unroll
+        for (int batch = 0; batch < 2; ++batch) {
+            const int tt0 = batch ? NB1 : 0, ntt = batch ? NB2 : NB1;
+            float v[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) v[i] = 0.0f;
+#pragma unroll
+            for (int bt = 0; bt < NB1; ++bt) {
+                if (bt < ntt) {
+                    const int tt = tt0 + bt;
+                    const float4 gv = *reinterpret_cast<const float4 *>(Gw + tt * 256);
+                    const float *pr = Pw + 4 * tt * KR;
+                    f32x2_t pv2[KP], v2[KP];
+#pragma unroll
+                    for (int kp = 0; kp < KP; ++kp) pv2[kp] = *reinterpret_cast<const f32x2_t *>(pr + 2 * kp);
+                    const float ge[4] = {gv.x, gv.y, gv.z, gv.w};
+                    ga2[0] += (f32x2_t){ge[0], ge[1]};
+                    ga2[1] += (f32x2_t){ge[2], ge[3]};
+                    gbt2[tt][0] += (f32x2_t){ge[0], ge[1]};
+                    gbt2[tt][1] += (f32x2_t){ge[2], ge[3]};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const f32x2_t gg = {ge[e], ge[e]};
+#pragma unroll
+                        for (int kp = 0; kp < KP; ++kp) {
+                            v2[kp] = e == 0 ? w2[e][kp] * gg : __builtin_elementwise_fma(w2[e][kp], gg, v2[kp]);
+#if DMN_MIX_ONE_PROBE != 3
+                            gw2[e][kp] = __builtin_elementwise_fma(gg, pv2[kp], gw2[e][kp]);
+#endif
+                        }
+                    }
+#pragma unroll
+                    for (int kp = 0; kp < KP; ++kp) { v[bt * KR + 2 * kp] = v2[kp].x; v[bt * KR + 2 * kp + 1] = v2[kp].y; }
+                }
+            }
+#if DMN_MIX_ONE_PROBE == 1
+#pragma unroll
+            for (int i = 1; i < 32; ++i) asm volatile("" ::"v"(v[i]));
+            tot[batch] = v[0];
+#else
+            tot[batch] = butterfly32(v);
+#endif
+        }
+#if DMN_MIX_ONE_PROBE == 2
+        asm volatile("" ::"v"(tot[0]), "v"(tot[1]), "v"(ga2[0]), "v"(ga2[1]));
+        continue;
+#endif
+        if (half == 1) { sm.red[buf][wq][0][lane] = tot[0]; sm.red[buf][wq][1][lane] = tot[1]; }
+        *reinterpret_cast<float4 *>(&sm.ga[buf][wq][half * 256 + lane * 4]) = make_float4(ga2[0].x, ga2[0].y, ga2[1].x, ga2[1].y);
+        __syncthreads();
+        // this block's share of gP: gathered over MIX_ONE_RUN pixels in LDS, written as 64-byte runs (one
+        // 4-byte store per value and pixel cost 8x its bytes in HBM writes: WRITE_SIZE 0.54 GB for 0.2 GB)
+        if (half == 0 && !(lane & 1)) {
+#pragma unroll
+            for (int batch = 0; batch < 2; ++batch) {
+                const int idx = lane >> 1, bt = idx / KR, k = idx - bt * KR;
+                const int tt = (batch ? NB1 : 0) + bt, t = wq + 4 * tt;
+                if (bt < (batch ? NB2 : NB1) && t < 4 * NW)
+                    sm.gp[t * KR + k][s & (MIX_ONE_RUN - 1)] = tot[batch] + sm.red[buf][wq][batch][lane];
+            }
+        }
+        if ((s & (MIX_ONE_RUN - 1)) == MIX_ONE_RUN - 1 || s == S - 1) {     // uniform
+            __syncthreads();
+            const int s0 = s & ~(MIX_ONE_RUN - 1), n = s - s0 + 1;
+            float *gpo = gPpart + (long long)cb * L * B * K * S;
+            if ((S & 3) == 0 && (n & 3) == 0) {
+                for (int i = tid; i < 4 * NW * KR * (MIX_ONE_RUN / 4); i += 512) {
+                    const int row = i / (MIX_ONE_RUN / 4), q = i - row * (MIX_ONE_RUN / 4);
+                    const int t = row / KR, k = row - t * KR;
+                    if (t < L && k < K && 4 * q < n)
+                        *reinterpret_cast<float4 *>(gpo + lbk_off(t, b, k, B, K, S) + s0 + 4 * q) =
+                            *reinterpret_cast<const float4 *>(&sm.gp[row][4 * q]);
+                }
+            } else {
+                for (int i = tid; i < 4 * NW * KR * MIX_ONE_RUN; i += 512) {
+                    const int row = i / MIX_ONE_RUN, q = i - row * MIX_ONE_RUN;
+                    const int t = row / KR, k = row - t * KR;
+                    if (t < L && k < K && q < n) gpo[lbk_off(t, b, k, B, K, S) + s0 + q] = sm.gp[row][q];
+                }
+            }
+        }
+        {
+            const int mcol = cb * MIX_ONE_COLS + tid;
+            if (mcol < M)
+                gA[((long long)b * S + s) * M + mcol] = (sm.ga[buf][0][tid] + sm.ga[buf][1][tid])
+                                                        + (sm.ga[buf][2][tid] + sm.ga[buf][3][tid]);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the look-ahead loads past the last pixel
+    if (mok) {
+#pragma unroll
+        for (int tt = 0; tt < NW; ++tt) {
+            const int t = wq + 4 * tt;
+            if (t < L)
+                *reinterpret_cast<float4 *>(gBt + ((long long)t * B + b) * M + m) =
+                    make_float4(gbt2[tt][0].x, gbt2[tt][0].y, gbt2[tt][1].x, gbt2[tt][1].y);
+        }
+        float *gwp = gWpart + (((long long)b * 4 + wq) * M + m) * K;   // rows m .. m+3 of this slab: 4*K adjacent floats
+        if (K == KR) {
+            float flat[4 * KR];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int kp = 0; kp < KP; ++kp) { flat[e * KR + 2 * kp] = gw2[e][kp].x; flat[e * KR + 2 * kp + 1] = gw2[e][kp].y; }
+#pragma unroll
+            for (int q = 0; q < KR; ++q)
+                *reinterpret_cast<float4 *>(gwp + 4 * q) = make_float4(flat[4 * q], flat[4 * q + 1], flat[4 * q + 2], flat[4 * q + 3]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int kp = 0; kp < KP; ++kp) {
+                    if (2 * kp < K) gwp[e * K + 2 * kp] = gw2[e][kp].x;
+                    if (2 * kp + 1 < K) gwp[e * K + 2 * kp + 1] = gw2[e][kp].y;
+                }
+        }
+    }
+}
+
+// gP[i] = sum over the column blocks of gPpart[cb][i], in block order
+__global__ void __launch_bounds__(256)
+mix_bwd_sum_parts(const float *__restrict__ part, float *__restrict__ out, long long n, int nparts)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float acc = part[i];
+    for (int p = 1; p < nparts; ++p) acc += part[(long long)p * n + i];
+    out[i] = acc;
+}
+
 static int check_mix(const char *fn, int B, int L, int K, int S, int M, int ldw)
 {
     if (B <= 0 || L <= 0 || K <= 0 || S <= 0 || M <= 0 || ldw < K)
@@ -498,22 +804,68 @@ extern "C" int dmn_mix_bcast_add(const float *A, const float *Bt, const float *P
     return launch_status("dmn_mix_bcast_add");
 }
 
+namespace dmn {
+// which backward runs: the one-pass kernel needs the model's K / L range and at least half a workgroup per CU
+// (B samples x 512-column blocks); DMN_MIX_BWD_ONE=0|1 forces the choice for A/B runs and tests
+static bool mix_bwd_one_pass(int B, int L, int K, int M)
+{
+    const int nw = (L + 3) / 4;
+    if (!(K <= MIX_BWD2_K && nw <= MIX_ONE_NW && M % 4 == 0)) return false;
+    const char *e = getenv("DMN_MIX_BWD_ONE");
+    if (e) return atoi(e) != 0;
+    const long long wgs = (long long)B * ((M + MIX_ONE_COLS - 1) / MIX_ONE_COLS);
+    return wgs >= NUM_CU / 2;
+}
+}  // namespace dmn
+
+extern "C" int dmn_mix_bwd_parts(int B, int L, int K, int S, int M)
+{
+    (void)S;
+    if (B <= 0 || L <= 0 || K <= 0 || M <= 0) return -1;
+    return mix_bwd_one_pass(B, L, K, M) ? 4 * B : L * B;
+}
+
+extern "C" long long dmn_mix_bwd_workspace_floats(int B, int L, int K, int S, int M)
+{
+    if (B <= 0 || L <= 0 || K <= 0 || S <= 0 || M <= 0) return -1;
+    if (!mix_bwd_one_pass(B, L, K, M)) return 0;
+    return (long long)((M + MIX_ONE_COLS - 1) / MIX_ONE_COLS) * L * B * K * S;
+}
+
 extern "C" int dmn_mix_bcast_add_bwd(const float *gQ, const float *P, const float *Wp, int ldw,
-                                     float *gA, float *gBt, float *gP, float *gWp_part, int B,
-                                     int L, int K, int S, int M, void *stream)
+                                     float *gA, float *gBt, float *gP, float *gWp_part, float *workspace,
+                                     int B, int L, int K, int S, int M, void *stream)
 {
     if (!gQ || !P || !Wp || !gA || !gBt || !gP || !gWp_part)
         return fail(-1, "dmn_mix_bcast_add_bwd: NULL pointer");
     if (int rc = check_mix("dmn_mix_bcast_add_bwd", B, L, K, S, M, ldw)) return rc;
     if (K > MIX_KMAX) return fail(-5, "dmn_mix_bcast_add_bwd: K=%d > %d not supported", K, MIX_KMAX);
+    hipStream_t s = (hipStream_t)stream;
+    if (M % 4 != 0 || ((uintptr_t)gQ & 15)) return fail(-5, "dmn_mix_bcast_add_bwd: M %% 4 == 0 and 16-byte aligned gQ required");
     const int nw = (L + 3) / 4;
+    if (mix_bwd_one_pass(B, L, K, M)) {
+        if (((uintptr_t)gA | (uintptr_t)gBt | (uintptr_t)gWp_part) & 15)
+            return fail(-5, "dmn_mix_bcast_add_bwd: gA, gBt and gWp_part must be 16-byte aligned");
+        if (!workspace) return fail(-1, "dmn_mix_bcast_add_bwd: this shape needs a workspace of dmn_mix_bwd_workspace_floats() floats");
+        const int ncb = (M + MIX_ONE_COLS - 1) / MIX_ONE_COLS;
+        dim3 grid(ncb, B);
+        // 156 KB of the CU's 160 KB LDS: opt in (cheap; per call, so that every device of the process gets it)
+        {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mix_bwd_one_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MixOneLds));
+            if (e != hipSuccess) return fail((int)e, "dmn_mix_bcast_add_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        }
+        hipLaunchKernelGGL(mix_bwd_one_kernel, grid, dim3(512), sizeof(MixOneLds), s, gQ, P, Wp, ldw, gA, gBt, workspace,
+                           gWp_part, B, L, K, S, M);
+        const long long n = (long long)L * B * K * S;
+        hipLaunchKernelGGL(mix_bwd_sum_parts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, workspace, gP, n, ncb);
+        return launch_status("dmn_mix_bcast_add_bwd");
+    }
     const bool gen2 = K <= MIX_BWD2_K && nw <= MIX_BWD2_NW && M % 4 == 0 && !(((uintptr_t)gA | (uintptr_t)gBt) & 15);
     if (M > 1024 && !gen2)
         return fail(-5, "dmn_mix_bcast_add_bwd: M=%d > 1024 needs K <= %d and L <= %d", M, MIX_BWD2_K, 4 * MIX_BWD2_NW);
     const size_t lds = (size_t)K * S * sizeof(float);
     if (lds > 64 * 1024) return fail(-5, "dmn_mix_bcast_add_bwd: K*S=%d too large for the LDS stage", K * S);
-    hipStream_t s = (hipStream_t)stream;
-    if (M % 4 != 0 || ((uintptr_t)gQ & 15)) return fail(-5, "dmn_mix_bcast_add_bwd: M %% 4 == 0 and 16-byte aligned gQ required");
     const char *pe = getenv("DMN_MIX_BWD_PIX2");
     if (gen2 && (M > 1024 || !(pe && atoi(pe) == 0))) {
         // pixels per workgroup: 5 when that divides S (S = 100 in training: 20 x B workgroups), else 4

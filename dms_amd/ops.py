@@ -451,10 +451,15 @@ class _MixBcastAdd(torch.autograd.Function):
             gA = torch.empty((B, S, M), device=dev, dtype=torch.float32)
             gBt = torch.empty((L, B, M), device=dev, dtype=torch.float32)
             gP = torch.empty((L, B, K, S), device=dev, dtype=torch.float32)
-            gWpp = torch.empty((L, B, M, K), device=dev, dtype=torch.float32)
+            # gWp leaves the library as `parts` (M, K) slabs (one per sample and word group, or per sample
+            # and word); wide rows at training batch sizes take the one-pass kernel, which wants a workspace
+            parts = _lib.query("dmn_mix_bwd_parts", B, L, K, S, M)
+            nws = _lib.query("dmn_mix_bwd_workspace_floats", B, L, K, S, M)
+            gWpp = torch.empty((parts, M, K), device=dev, dtype=torch.float32)
+            ws = torch.empty((nws,), device=dev, dtype=torch.float32) if nws > 0 else None
             _lib.call("dmn_mix_bcast_add_bwd", _ptr(gQ), _ptr(P), _ptr(Wp), Wp.stride(0),
-                      _ptr(gA), _ptr(gBt), _ptr(gP), _ptr(gWpp), B, L, K, S, M, _stream())
-        return gA, gBt, gP, gWpp.sum(dim=(0, 1))
+                      _ptr(gA), _ptr(gBt), _ptr(gP), _ptr(gWpp), _ptr(ws), B, L, K, S, M, _stream())
+        return gA, gBt, gP, gWpp.sum(dim=0)
 
 
 def mix_bcast_add(A, Bt, P, Wp):

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DMN_ABI_VERSION 2
+#define DMN_ABI_VERSION 3
 
 /* activation ids of the SRU cell (upstream `use_tanh` / `use_relu` switches) */
 #define DMN_ACT_IDENTITY 0
@@ -222,13 +222,23 @@ int dmn_mix_sru_fwd(const float *A, const float *Bt, const float *Pt, const floa
                     int B, int L, int K, int S, int d, int act, void *stream);
 
 /*
- * gradients of dmn_mix_bcast_add w.r.t. A, Bt, P, Wp given gQ (S*L, B, M):
+ * gradients of dmn_mix_bcast_add w.r.t. A, Bt, P, Wp given gQ (S*L, B, M) -- autograd of dmn.py:187-201
+ * in the training step (train.py:275-290):
  *   gA[b,s,m] = sum_t gQ ; gBt[t,b,m] = sum_s gQ ; gP[t,b,k,s] = sum_m Wp[m,k] gQ ;
- *   gWp_part (L, B, M, K) partial sums per (word, batch entry) (caller reduces over L, B).
- *   Limits: K <= 16, M <= 1024, M % 4 == 0.
+ *   gWp_part (parts, M, K): partial sums of gWp[m,k] = sum_{t,b,s} gQ * P; the caller adds the `parts`
+ *   slabs, parts = dmn_mix_bwd_parts(B, L, K, S, M).
+ * Two implementations, chosen by shape (same choice in the two query functions):
+ *   - ONE pass over gQ (K <= 10, L <= 20, M % 4 == 0 and B * ceil(M / 512) >= 128 workgroups): a workgroup
+ *     owns 512 columns of one sample and walks all its pixels; parts = 4*B; `workspace` holds
+ *     dmn_mix_bwd_workspace_floats() floats (per-column-block shares of gP, added in block order:
+ *     deterministic).  gQ, gA, gBt, gWp_part 16-byte aligned.
+ *   - two passes (pixel pass gA / gP, word pass gBt / gWp) otherwise: parts = L*B, workspace unused (may be
+ *     NULL); K <= 16, M % 4 == 0; rows wider than 1024 floats need K <= 10 and L <= 24.
  */
+int dmn_mix_bwd_parts(int B, int L, int K, int S, int M);
+long long dmn_mix_bwd_workspace_floats(int B, int L, int K, int S, int M);
 int dmn_mix_bcast_add_bwd(const float *gQ, const float *P, const float *Wp, int ldw,
-                          float *gA, float *gBt, float *gP, float *gWp_part,
+                          float *gA, float *gBt, float *gP, float *gWp_part, float *workspace,
                           int B, int L, int K, int S, int M, void *stream);
 
 /*

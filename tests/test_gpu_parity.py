@@ -432,6 +432,7 @@ def test_mix_bcast_add_bwd_matches_autograd(B, L, K, S, M, monkeypatch):
     rs = [t.clone().double().requires_grad_(True) for t in (A, Bt, P, Wp)]
     (_mix_ref(*rs) * gQ.double()).sum().backward()
     got = {}
+    monkeypatch.setenv("DMN_MIX_BWD_ONE", "0")                     # the two-pass kernels
     for mode in (("1", "0") if M <= 1024 else ("1", "1")):        # rows wider than 1024: round-2 kernels only
         monkeypatch.setenv("DMN_MIX_BWD_PIX2", mode)
         monkeypatch.setenv("DMN_MIX_BWD_WORD2", mode)
@@ -442,6 +443,20 @@ def test_mix_bcast_add_bwd_matches_autograd(B, L, K, S, M, monkeypatch):
         got[mode] = [a.grad.cpu() for a in gs]
     for a, b, n in zip(got["1"], got.get("0", got["1"]), "A Bt P Wp".split()):
         assert rel_err(a, b) < 2e-6, n
+    if K <= 10 and L <= 20:
+        # the one-pass kernel (round 3): same sums, gA / gBt in the same order as the two-pass kernels
+        monkeypatch.setenv("DMN_MIX_BWD_ONE", "1")
+        monkeypatch.setenv("DMN_MIX_BWD_PIX2", "1")
+        monkeypatch.setenv("DMN_MIX_BWD_WORD2", "1")
+        gs = [t.to(DEV).requires_grad_(True) for t in (A, Bt, P, Wp)]
+        (ops.mix_bcast_add(*gs) * gQ.to(DEV)).sum().backward()
+        for a, b, n in zip(gs, rs, "A Bt P Wp".split()):
+            assert rel_err(a.grad.cpu(), b.grad) < 1e-5, ("one-pass", n)
+        assert torch.equal(gs[0].grad.cpu(), got["1"][0]) and torch.equal(gs[1].grad.cpu(), got["1"][1])
+        again = [t.to(DEV).requires_grad_(True) for t in (A, Bt, P, Wp)]
+        (ops.mix_bcast_add(*again) * gQ.to(DEV)).sum().backward()
+        for a, b in zip(gs, again):                                # deterministic: no atomics anywhere
+            assert torch.equal(a.grad, b.grad)
 
 
 @pytest.mark.parametrize("B,Cx,Cf,H,W", [(2, 3, 5, 4, 6), (1, 7, 0, 3, 3), (1, 0, 4, 1, 1), (2, 2, 2, 5, 7),
