@@ -98,7 +98,7 @@ class LaunchTimer(object):
             return ("sru_fwd k=%d T=%d cols=%d -> (B, d, H, W) image" % (k, T, B * d),
                     (4 * k + (4 if k == 3 else 0) + 4) * T * B * d)
         if name == "dmn_sru_bwd":
-            T, B, d, k = args[11:15]
+            T, B, d, k = args[12:16]
             per = (4 * k + (4 if k == 3 else 0) + 8) + (4 * k + (4 if k == 3 else 0))
             return "sru_bwd k=%d T=%d cols=%d" % (k, T, B * d), per * T * B * d
         if name == "dmn_dynfilter_bwd":
@@ -147,7 +147,7 @@ class LaunchTimer(object):
             T, B, d = args[5:8]
             return "sru_state fwd +c (u0|f only) T=%d cols=%d" % (T, B * d), 12 * T * B * d
         if name == "dmn_sru_state_bwd":
-            T, B, d = args[8:11]
+            T, B, d = args[9:12]
             return "sru_state bwd (u0|f only) T=%d cols=%d" % (T, B * d), 20 * T * B * d
         if name == "dmn_gconv3x3_bn_relu":
             N, C, H, W = args[9:13]

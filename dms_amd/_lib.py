@@ -20,13 +20,13 @@ _ll = ctypes.c_longlong
 # name -> argtypes, mirrors include/dmn_hip.h one to one
 SIGNATURES = {
     "dmn_sru_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p],
-    "dmn_sru_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
+    "dmn_sru_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
     "dmn_sru_fwd_scan": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _p],
     "dmn_sru_fwd_image": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _ll, _i, _p],
     "dmn_sru_fwd_scan_noalloc": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _p],
     "dmn_sru_state_fwd": [_p, _p, _p, _p, _i, _i, _i, _p],
     "dmn_sru_state_fwd_train": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
-    "dmn_sru_state_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "dmn_sru_state_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "dmn_sru_state_fwd_scan": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "dmn_sru_scan_workspace_floats": [_i, _i, _i, _i],
     "dmn_bias_sigmoid": [_p, _p, _ll, _i, _p],

@@ -121,7 +121,7 @@ sru_bwd_cols(const float *__restrict__ U, const float *__restrict__ x,
              const float *__restrict__ grad_last,
              float *__restrict__ grad_U, float *__restrict__ grad_x,
              float *__restrict__ grad_bias, float *__restrict__ grad_c0,
-             int T, int ncols, int d, float scale_x)
+             int T, int ncols, int d, float scale_x, float *__restrict__ gb_part)
 {
     constexpr int NLD = (K == 3) ? 4 : (K == 4 ? 3 : 2);      // VMEM loads per step
     constexpr int NST = DMN_VMCNT_COUNT_STORES ? ((K == 3) ? 2 : 1) : 0;   // VMEM stores per step that a wait may leave outstanding (sru_ring.h)
@@ -296,21 +296,42 @@ sru_bwd_cols(const float *__restrict__ U, const float *__restrict__ x,
             finish(c0v, rGU, rGX, 0u, 0u);                                  // time 0: c_{-1} = c0
         }
     }
-    // batch reduction of the bias gradient: one hardware float atomic per lane and gate
-    unsafeAtomicAdd(grad_bias + j, gb1);
-    if (K != 2) unsafeAtomicAdd(grad_bias + d + j, gb2);
+    // batch reduction of the bias gradient.  gb_part given: the column's sums go to gb_part (2, ncols) and
+    // sru_bwd_bias_reduce adds them over the batch in sample order (what the reference's Python does with its
+    // (2, B, d) partials): the same bits on every launch.  NULL: one hardware float atomic per lane and gate
+    // (the order of the B additions per address is not fixed).
+    if (gb_part) {
+        gb_part[col] = gb1;
+        if (K != 2) gb_part[(size_t)ncols + col] = gb2;
+    } else {
+        unsafeAtomicAdd(grad_bias + j, gb1);
+        if (K != 2) unsafeAtomicAdd(grad_bias + d + j, gb2);
+    }
     grad_c0[col] = cur;
+}
+
+// grad_bias[g*d + j] = sum over b (ascending) of part[g*ncols + b*d + j], g < ngates
+__global__ void __launch_bounds__(256)
+sru_bwd_bias_reduce(const float *__restrict__ part, float *__restrict__ grad_bias, int B, int d, int ngates)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ngates * d) return;
+    const int g = i / d, j = i - g * d;
+    const float *p = part + (size_t)g * B * d + j;
+    float acc = 0.0f;
+    for (int b = 0; b < B; ++b) acc += p[(size_t)b * d];
+    grad_bias[i] = acc;
 }
 
 template <int K, int DEPTH>
 static void launch_bwd_act(int act, dim3 grid, hipStream_t s, const float *U, const float *x,
                            const float *bias, const float *c0, const float *c_all,
                            const float *grad_h, const float *grad_last, float *grad_U, float *grad_x,
-                           float *gb, float *grad_c0, int T, int ncols, int d, float scale_x)
+                           float *gb, float *grad_c0, int T, int ncols, int d, float scale_x, float *gb_part)
 {
 #define DMN_BWD(A)                                                                                 \
     hipLaunchKernelGGL((sru_bwd_cols<K, A, DEPTH>), grid, dim3(WAVE), 0, s, U, x, bias, c0, c_all, \
-                       grad_h, grad_last, grad_U, grad_x, gb, grad_c0, T, ncols, d, scale_x)
+                       grad_h, grad_last, grad_U, grad_x, gb, grad_c0, T, ncols, d, scale_x, gb_part)
     if (act == DMN_ACT_TANH) DMN_BWD(DMN_ACT_TANH);
     else if (act == DMN_ACT_RELU) DMN_BWD(DMN_ACT_RELU);
     else DMN_BWD(DMN_ACT_IDENTITY);
@@ -323,7 +344,7 @@ using namespace dmn;
 
 extern "C" int dmn_sru_state_bwd(const float *U2, const float *bias, const float *c0, const float *c_all,
                                  const float *grad_last, float *grad_U2, float *grad_bias_f, float *grad_c0,
-                                 int T, int B, int d, void *stream)
+                                 float *bias_partials, int T, int B, int d, void *stream)
 {
     const char *fn = "dmn_sru_state_bwd";
     if ((!U2 && T > 0) || !bias || !grad_bias_f || !grad_c0) return fail(-1, "%s: NULL pointer", fn);
@@ -333,28 +354,32 @@ extern "C" int dmn_sru_state_bwd(const float *U2, const float *bias, const float
     if (((uintptr_t)U2 | (uintptr_t)grad_U2) & 7) return fail(-7, "%s: U2 and grad_U2 must be 8-byte aligned", fn);
     const int ncols = B * d;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(grad_bias_f, 0, sizeof(float) * (size_t)d, s);
-    if (e != hipSuccess) return fail((int)e, "%s: hipMemsetAsync(grad_bias_f): %s", fn, hipGetErrorString(e));
+    if (!bias_partials) {
+        hipError_t e = hipMemsetAsync(grad_bias_f, 0, sizeof(float) * (size_t)d, s);
+        if (e != hipSuccess) return fail((int)e, "%s: hipMemsetAsync(grad_bias_f): %s", fn, hipGetErrorString(e));
+    }
     const char *env = getenv("DMN_SRU_BWD_DEPTH");
     int depth = env ? atoi(env) : 0;
     if (depth <= 0) depth = 8;   // tools/state_train_bench.py, 1005 waves: 76.2 % of 8 TB/s at 8, 71 % at 6, 74 % at 16
     dim3 grid((ncols + WAVE - 1) / WAVE);
     // K = 2 reads bias[j] (forget) only; grad_bias_f has d entries (the reset half has no gradient here)
 #define DMN_SB(DV) hipLaunchKernelGGL((sru_bwd_cols<2, DMN_ACT_IDENTITY, DV>), grid, dim3(WAVE), 0, s, U2, (const float *)nullptr, bias, c0, c_all, \
-                                      (const float *)nullptr, grad_last, grad_U2, (float *)nullptr, grad_bias_f, grad_c0, T, ncols, d, 1.0f)
+                                      (const float *)nullptr, grad_last, grad_U2, (float *)nullptr, grad_bias_f, grad_c0, T, ncols, d, 1.0f, bias_partials)
     if (depth <= 3) DMN_SB(3);
     else if (depth <= 4) DMN_SB(4);
     else if (depth <= 6) DMN_SB(6);
     else if (depth <= 8) DMN_SB(8);
     else DMN_SB(16);
 #undef DMN_SB
+    if (bias_partials)
+        hipLaunchKernelGGL(sru_bwd_bias_reduce, dim3((d + 255) / 256), dim3(256), 0, s, bias_partials, grad_bias_f, B, d, 1);
     return launch_status(fn);
 }
 
 extern "C" int dmn_sru_bwd(const float *U, const float *x, const float *bias, const float *c0,
                            const float *c_all, const float *grad_h, const float *grad_last,
                            float *grad_U, float *grad_x, float *grad_bias, float *grad_c0,
-                           int T, int B, int d, int k, int act, float scale_x, void *stream)
+                           float *bias_partials, int T, int B, int d, int k, int act, float scale_x, void *stream)
 {
     const char *fn = "dmn_sru_bwd";
     if ((!U && T > 0) || !bias) return fail(-1, "%s: U and bias must not be NULL", fn);
@@ -372,9 +397,11 @@ extern "C" int dmn_sru_bwd(const float *U, const float *x, const float *bias, co
     const int ncols = B * d;
     dim3 grid((ncols + WAVE - 1) / WAVE);
     hipStream_t s = (hipStream_t)stream;
-    // the kernel ADDS its per-column sums into grad_bias: start from zero (no allocation, same stream)
-    hipError_t e = hipMemsetAsync(grad_bias, 0, sizeof(float) * 2 * (size_t)d, s);
-    if (e != hipSuccess) return fail((int)e, "%s: hipMemsetAsync(grad_bias): %s", fn, hipGetErrorString(e));
+    if (!bias_partials) {
+        // the kernel ADDS its per-column sums into grad_bias: start from zero (no allocation, same stream)
+        hipError_t e = hipMemsetAsync(grad_bias, 0, sizeof(float) * 2 * (size_t)d, s);
+        if (e != hipSuccess) return fail((int)e, "%s: hipMemsetAsync(grad_bias): %s", fn, hipGetErrorString(e));
+    }
     // tuning / test hook: DMN_SRU_BWD_DEPTH=<n> forces the ring depth (read on every call)
     const char *env = getenv("DMN_SRU_BWD_DEPTH");
     int depth = env ? atoi(env) : 0;
@@ -384,16 +411,18 @@ extern "C" int dmn_sru_bwd(const float *U, const float *x, const float *bias, co
     if (depth <= 0) depth = 4;
 #define DMN_BWD_K(KV)                                                                                                                             \
     do {                                                                                                                                          \
-        if (depth <= 2) launch_bwd_act<KV, 2>(act, grid, s, U, x, bias, c0, c_all, grad_h, grad_last, grad_U, grad_x, grad_bias, grad_c0, T, ncols, d, scale_x);        \
-        else if (depth <= 3) launch_bwd_act<KV, 3>(act, grid, s, U, x, bias, c0, c_all, grad_h, grad_last, grad_U, grad_x, grad_bias, grad_c0, T, ncols, d, scale_x);        \
-        else if (depth <= 4) launch_bwd_act<KV, 4>(act, grid, s, U, x, bias, c0, c_all, grad_h, grad_last, grad_U, grad_x, grad_bias, grad_c0, T, ncols, d, scale_x);        \
-        else if (depth <= 6) launch_bwd_act<KV, 6>(act, grid, s, U, x, bias, c0, c_all, grad_h, grad_last, grad_U, grad_x, grad_bias, grad_c0, T, ncols, d, scale_x);   \
-        else if (depth <= 8) launch_bwd_act<KV, 8>(act, grid, s, U, x, bias, c0, c_all, grad_h, grad_last, grad_U, grad_x, grad_bias, grad_c0, T, ncols, d, scale_x);   \
-        else if (depth <= 12) launch_bwd_act<KV, 12>(act, grid, s, U, x, bias, c0, c_all, grad_h, grad_last, grad_U, grad_x, grad_bias, grad_c0, T, ncols, d, scale_x); \
-        else launch_bwd_act<KV, 16>(act, grid, s, U, x, bias, c0, c_all, grad_h, grad_last, grad_U, grad_x, grad_bias, grad_c0, T, ncols, d, scale_x);                  \
+        if (depth <= 2) launch_bwd_act<KV, 2>(act, grid, s, U, x, bias, c0, c_all, grad_h, grad_last, grad_U, grad_x, grad_bias, grad_c0, T, ncols, d, scale_x, bias_partials);        \
+        else if (depth <= 3) launch_bwd_act<KV, 3>(act, grid, s, U, x, bias, c0, c_all, grad_h, grad_last, grad_U, grad_x, grad_bias, grad_c0, T, ncols, d, scale_x, bias_partials);        \
+        else if (depth <= 4) launch_bwd_act<KV, 4>(act, grid, s, U, x, bias, c0, c_all, grad_h, grad_last, grad_U, grad_x, grad_bias, grad_c0, T, ncols, d, scale_x, bias_partials);        \
+        else if (depth <= 6) launch_bwd_act<KV, 6>(act, grid, s, U, x, bias, c0, c_all, grad_h, grad_last, grad_U, grad_x, grad_bias, grad_c0, T, ncols, d, scale_x, bias_partials);   \
+        else if (depth <= 8) launch_bwd_act<KV, 8>(act, grid, s, U, x, bias, c0, c_all, grad_h, grad_last, grad_U, grad_x, grad_bias, grad_c0, T, ncols, d, scale_x, bias_partials);   \
+        else if (depth <= 12) launch_bwd_act<KV, 12>(act, grid, s, U, x, bias, c0, c_all, grad_h, grad_last, grad_U, grad_x, grad_bias, grad_c0, T, ncols, d, scale_x, bias_partials); \
+        else launch_bwd_act<KV, 16>(act, grid, s, U, x, bias, c0, c_all, grad_h, grad_last, grad_U, grad_x, grad_bias, grad_c0, T, ncols, d, scale_x, bias_partials);                  \
     } while (0)
     if (k == 3) DMN_BWD_K(3);
     else        DMN_BWD_K(4);
 #undef DMN_BWD_K
+    if (bias_partials)
+        hipLaunchKernelGGL(sru_bwd_bias_reduce, dim3((2 * d + 255) / 256), dim3(256), 0, s, bias_partials, grad_bias, B, d, 2);
     return launch_status(fn);
 }

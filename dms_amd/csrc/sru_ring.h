@@ -20,13 +20,16 @@ constexpr float LOG2E = 1.4426950408889634f;
 #define DMN_ST_AUX 2
 #endif
 
-// Counted waits and stores.  A ring slot is waited for with s_waitcnt vmcnt(N), N = the number of
-// YOUNGER vector-memory operations that may stay outstanding.  Loads return in order among themselves;
-// whether a store's acknowledge is ordered against the loads around it on this counter is not stated
-// in the material at hand, so N counts the younger LOADS only (0): if stores do complete in order the
-// wait is a little stricter than needed, if they do not it is still right.  Measured cost: none (scans
-// and backward within 0.5 % of the old count once the backward ring is one slot deeper;
-// tools/sru_bwd_bench.py, tools/scan_bench.py).  1 = count the younger stores too, for A/B runs.
+// Counted waits and stores: ONE policy for the library.  Vector-memory loads and stores retire IN ORDER on the one
+// vmcnt counter: s_waitcnt vmcnt(N) guarantees every operation but the N youngest, whatever their kind.  That is
+// hipcc's own model for this target family (no separate store counter: SIInsertWaitcnts counts loads and stores as
+// one event type; for load / store / use-of-load it emits vmcnt(1) -- tools/probe/vmcnt_order.hip, checked by
+// tests/test_asm_audit.py) and every compiler-scheduled kernel of this library depends on it; mix_sru.hip's
+// hand-counted waits (N = the younger h stores) and mix.hip's (N = the younger LDS-DMA loads) use it directly.
+// The scan rings below count the younger LOADS only (0): with the younger stores left out a wait is merely
+// stricter than needed, and that setting is what measured fastest once the ring depths were re-tuned for it
+// (tools/sru_bwd_bench.py, tools/scan_bench.py; 72.3 % -> 74.8 % on the roofline kernel).  1 = count the
+// younger stores too (equally valid), for A/B runs.
 #ifndef DMN_VMCNT_COUNT_STORES
 #define DMN_VMCNT_COUNT_STORES 0
 #endif

@@ -260,6 +260,14 @@ def sru_state(u2, bias, c0=None, nchunks=None):
     return c_last
 
 
+def _bias_partials(n, device):
+    """Scratch for the deterministic batch reduction of the bias gradient (sample order, as the reference sums its
+    (2, B, d) partials): the default.  DMN_SRU_BWD_ATOMIC=1 -> None: in-kernel float atomics, order not fixed."""
+    if os.environ.get("DMN_SRU_BWD_ATOMIC") == "1":
+        return None
+    return torch.empty((n,), device=device, dtype=torch.float32)
+
+
 class _SRUStateCompute(torch.autograd.Function):
     """Autograd node of the state-only scan: c_last from u2 = [u0 | forget] (training: the steps of the
     last mSRU layer whose hidden state nothing reads, so only the cell-state chain carries gradient)."""
@@ -284,8 +292,9 @@ class _SRUStateCompute(torch.autograd.Function):
             gu2 = torch.empty_like(u2)
             gbf = torch.empty((d,), device=u2.device, dtype=torch.float32)
             gc0 = torch.empty((B, d), device=u2.device, dtype=torch.float32)
+            part = _bias_partials(B * d, u2.device)
             _lib.call("dmn_sru_state_bwd", _ptr(u2), _ptr(bias), _ptr(c0), _ptr(c_all), _ptr(grad_last),
-                      _ptr(gu2), _ptr(gbf), _ptr(gc0), T, B, d, _stream())
+                      _ptr(gu2), _ptr(gbf), _ptr(gc0), _ptr(part), T, B, d, _stream())
         gbias = torch.cat([gbf, torch.zeros_like(gbf)]) if ctx.needs_input_grad[1] else None
         return gu2, gbias, (gc0 if c0 is not None and ctx.needs_input_grad[2] else None)
 
@@ -321,10 +330,11 @@ class _SRUCompute(torch.autograd.Function):
         with torch.cuda.device(u.device):
             gu = torch.empty_like(u)
             gx = torch.empty((T, B, d), device=u.device, dtype=torch.float32) if k == 3 else None
-            gbias = torch.empty((2 * d,), device=u.device, dtype=torch.float32)   # summed over t and b in-kernel
+            gbias = torch.empty((2 * d,), device=u.device, dtype=torch.float32)   # summed over t and b by the library
             gc0 = torch.empty((B, d), device=u.device, dtype=torch.float32)
+            part = _bias_partials(2 * B * d, u.device)
             _lib.call("dmn_sru_bwd", _ptr(u), _ptr(x), _ptr(bias), _ptr(c0), _ptr(c_all),
-                      _ptr(grad_h), _ptr(grad_last), _ptr(gu), _ptr(gx), _ptr(gbias), _ptr(gc0),
+                      _ptr(grad_h), _ptr(grad_last), _ptr(gu), _ptr(gx), _ptr(gbias), _ptr(gc0), _ptr(part),
                       T, B, d, k, ACT_IDS[ctx.act], float(ctx.scale_x), _stream())
         return gu, gx, gbias, (gc0 if c0 is not None else None), None, None
 

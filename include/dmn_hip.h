@@ -119,13 +119,14 @@ int dmn_sru_state_fwd(const float *U2, const float *bias, const float *c0, float
  *   c_all (T, B, d);
  * the backward takes dL/dc_last (grad_last (B, d) or NULL = 0) and returns
  *   grad_U2 (T, B, d, 2), grad_bias_f (d) = the forget half of the bias gradient (summed over time and
- *   batch in the kernel; the reset half is zero for these steps), grad_c0 (B, d).
+ *   batch; the reset half is zero for these steps), grad_c0 (B, d);
+ *   bias_partials: B*d floats of caller scratch or NULL, as for dmn_sru_bwd.
  */
 int dmn_sru_state_fwd_train(const float *U2, const float *bias, const float *c0, float *c_all,
                             float *c_last, int T, int B, int d, void *stream);
 int dmn_sru_state_bwd(const float *U2, const float *bias, const float *c0, const float *c_all,
                       const float *grad_last, float *grad_U2, float *grad_bias_f, float *grad_c0,
-                      int T, int B, int d, void *stream);
+                      float *bias_partials, int T, int B, int d, void *stream);
 /* time-parallel variant for FEW columns (batch-1 serving), as dmn_sru_fwd_scan is to dmn_sru_fwd:
  * chunk aggregates (prod f, c | c_in = 0) composed in time order; `workspace` holds
  * dmn_sru_scan_workspace_floats(T, B, d, nchunks) floats, caller-owned, 8-byte aligned. */
@@ -137,15 +138,18 @@ int dmn_sru_state_fwd_scan(const float *U2, const float *bias, const float *c0, 
  * of the same package (autograd of dmn.py:156,204).
  *   c_all (T,B,d) saved by the forward; grad_h (T,B,d); grad_last (B,d) or NULL.
  *   grad_U (T,B,d,k); grad_x (T,B,d) iff k == 3 else NULL;
- *   grad_bias (2*d) = [forget | reset], summed over time AND batch inside the kernel (the entry
- *   point zeroes it on `stream` first, every lane adds its column's sums with one float atomic:
- *   no (2,B,d) partials for the caller to reduce; the order of the B additions per entry is not
- *   fixed, so the last bit may differ between launches);
+ *   grad_bias (2*d) = [forget | reset], summed over time AND batch by the library:
+ *     bias_partials != NULL (2*B*d floats of caller scratch): every column's sums over time go there and a
+ *       second small launch adds them over the batch in sample order -- what the reference's Python does with
+ *       the kernel's (2, B, d) partials -- so two launches on the same inputs give the same bits;
+ *     bias_partials == NULL: the entry point zeroes grad_bias on `stream` and every lane adds its column's
+ *       sums with one float atomic; the order of the B additions per entry is not fixed, so the last bit may
+ *       differ between launches;
  *   grad_c0 (B, d).
  */
 int dmn_sru_bwd(const float *U, const float *x, const float *bias, const float *c0,
                 const float *c_all, const float *grad_h, const float *grad_last,
-                float *grad_U, float *grad_x, float *grad_bias, float *grad_c0,
+                float *grad_U, float *grad_x, float *grad_bias, float *grad_c0, float *bias_partials,
                 int T, int B, int d, int k, int act, float scale_x, void *stream);
 
 /*

@@ -433,6 +433,22 @@ def test_config4_training_scans_T2000_B64_d1005_forward_with_c_and_backward_colu
     want_b = gb_r[:, 0, 9:].sum(axis=1)
     got_b = torch.stack([bg.grad[17], bg.grad[d + 17]]).cpu().numpy()
     np.testing.assert_allclose(got_b, want_b, rtol=5e-4, atol=1e-3)
+    # the batch reduction runs in sample order: a second backward on the same inputs gives the same bits
+    ug2, bg2, cg2 = u.clone().requires_grad_(True), bias.clone().requires_grad_(True), c0.clone().requires_grad_(True)
+    xg2 = x.clone().requires_grad_(True) if x is not None else None
+    h2, cl2 = ops.sru_compute(ug2, xg2, bg2, cg2, "tanh", 1.0)
+    ((h2 * gh).sum() + (cl2 * gl).sum()).backward()
+    assert torch.equal(bg2.grad, bg.grad) and torch.equal(ug2.grad, ug.grad)
+    # ... and the atomic form (DMN_SRU_BWD_ATOMIC=1) agrees with it to rounding
+    os.environ["DMN_SRU_BWD_ATOMIC"] = "1"
+    try:
+        ug3, bg3, cg3 = u.clone().requires_grad_(True), bias.clone().requires_grad_(True), c0.clone().requires_grad_(True)
+        xg3 = x.clone().requires_grad_(True) if x is not None else None
+        h3, cl3 = ops.sru_compute(ug3, xg3, bg3, cg3, "tanh", 1.0)
+        ((h3 * gh).sum() + (cl3 * gl).sum()).backward()
+    finally:
+        os.environ.pop("DMN_SRU_BWD_ATOMIC", None)
+    assert rel_err(bg3.grad.cpu(), bg.grad.cpu()) < 1e-5
 
 
 # ------------------------------------------------------------------------------------

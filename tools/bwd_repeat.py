@@ -27,7 +27,7 @@ def fwd():
 def bwd(c_all):
     gu = torch.empty_like(u); gx = torch.empty_like(gh) if k == 3 else None
     gb = torch.empty(2 * d, device=DEV); gc0 = torch.empty((B, d), device=DEV)
-    _lib.call("dmn_sru_bwd", P(u), P(x), P(bias), P(c0), P(c_all), P(gh), P(gl), P(gu), P(gx), P(gb), P(gc0),
+    _lib.call("dmn_sru_bwd", P(u), P(x), P(bias), P(c0), P(c_all), P(gh), P(gl), P(gu), P(gx), P(gb), P(gc0), None,
               T, B, d, k, 1, 1.0, s)
     return gu, gx, gc0
 

@@ -38,7 +38,7 @@ if which in ("bwd", "all"):
         Pp = lambda t: None if t is None else t.data_ptr()
         for _ in range(REPS):
             _lib.call("dmn_sru_bwd", Pp(u), Pp(x), Pp(bias), None, Pp(c_all), Pp(gh), None, Pp(gu), Pp(gx),
-                      Pp(gb), Pp(gc0), T, B, d, k, 1, 1.0, s)
+                      Pp(gb), Pp(gc0), None, T, B, d, k, 1, 1.0, s)
         torch.cuda.synchronize()
         del u, x, gh, c_all, gu, gx
 if which in ("tap", "all"):

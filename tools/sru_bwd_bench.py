@@ -27,7 +27,7 @@ for k in (3, 4):
     for depth in ("2", "3", "4", "6", "8", "12", "16"):
         os.environ["DMN_SRU_BWD_DEPTH"] = depth
         call = lambda: _lib.call("dmn_sru_bwd", P(u), P(x), P(bias), P(c0), P(c_all), P(gh), P(gl), P(gu), P(gx),
-                                 P(gb), P(gc0), T, B, d, k, 1, 1.0, s)
+                                 P(gb), P(gc0), None, T, B, d, k, 1, 1.0, s)
         for _ in range(3):
             call()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

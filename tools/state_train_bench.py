@@ -34,5 +34,5 @@ for depth in (4, 6, 8, 16, 24, 32):
 os.environ.pop("DMN_SRU_DEPTH")
 for depth in (3, 4, 6, 8, 16):
     os.environ["DMN_SRU_BWD_DEPTH"] = str(depth)
-    ms = timeit(lambda: _lib.call("dmn_sru_state_bwd", P(u2), P(bias), None, P(c_all), P(gl), P(gu), P(gb), P(gc0), T, B, d, st))
+    ms = timeit(lambda: _lib.call("dmn_sru_state_bwd", P(u2), P(bias), None, P(c_all), P(gl), P(gu), P(gb), P(gc0), None, T, B, d, st))
     print("state bwd    depth %2d: %.4f ms  %.0f GB/s (%.1f %%)" % (depth, ms, 20.0 * T * B * d / ms / 1e6, 20.0 * T * B * d / ms / 8e7), flush=True)
