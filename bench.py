@@ -197,6 +197,9 @@ class LaunchTimer(object):
         if name == "dmn_mix_sru_fwd":
             B, L, K, S, d = args[9:14]
             return 2 * B * S * L * d * 4 * K
+        if name == "dmn_dynfilter_bwd":                      # two thin GEMMs: gF = gP . V^T and gV = F^T . gP
+            B, L, K, C, S = args[5:10]
+            return 2 * 2 * B * L * K * C * S
         return 0
 
     def summary(self):

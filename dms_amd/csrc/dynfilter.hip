@@ -10,6 +10,7 @@
 // Rows r = (t, k) of F / P are addressed in place in the reference's (L, B, K, .) layout,
 // so no permuted copy of the filters is ever made.
 #include "common.h"
+#include "sru_ring.h"
 
 namespace dmn {
 
@@ -20,6 +21,25 @@ __device__ __forceinline__ long long lbk_row(int r, int b, int B, int K, int ld)
 {
     const int t = r / K, k = r - t * K;
     return ((long long)(t * B + b) * K + k) * ld;
+}
+
+
+// XCD-aware tile order.  The hardware deals consecutive workgroups to the 8 XCDs round-robin, and each XCD has its
+// own L2: with (x, y, b) taken straight from blockIdx the 16 tiles of one sample -- which share its filter rows and
+// its feature columns -- land on all 8 XCDs and every L2 fetches the sample's operands for itself (measured at
+// B = 32: ~50 TFLOP/s whichever kernel, 700 MB of operand traffic crossing the fabric for 157 MB of tensors).
+// With a 1-D grid and tile id v = (block % 8) * chunk + block / 8, XCD k works through the CONSECUTIVE ids
+// [k * chunk, (k + 1) * chunk): a sample's tiles meet in one L2.  Returns false for the padding blocks.
+__device__ __forceinline__ bool xcd_tile(int nx, int ny, int nz, int &x, int &y, int &z)
+{
+    const int total = nx * ny * nz, chunk = (total + 7) / 8;
+    const int i = (int)blockIdx.x;
+    const int v = (i % 8) * chunk + i / 8;
+    if (v >= total) return false;
+    x = v % nx;
+    y = (v / nx) % ny;
+    z = v / (nx * ny);
+    return true;
 }
 
 // ---- forward, vector path: C % 4 == 0, S % 4 == 0, 16-byte aligned bases -------------
@@ -37,8 +57,10 @@ dynfilter_fwd_vec(const float *__restrict__ V, const float *__restrict__ F, floa
 {
     __shared__ float As[BK][BM + PAD];   // As[kk][row]  (transposed on store)
     __shared__ float Bs[BK][BN + PAD];   // Bs[kk][col]
-    const int b = SPLIT ? (int)blockIdx.z / nch : (int)blockIdx.z, ch = SPLIT ? (int)blockIdx.z % nch : 0;
-    const int r0 = blockIdx.y * BM, s0 = blockIdx.x * BN;
+    int bx, by, bz;
+    if (!xcd_tile((S + BN - 1) / BN, (R + BM - 1) / BM, SPLIT ? B * nch : B, bx, by, bz)) return;
+    const int b = SPLIT ? bz / nch : bz, ch = SPLIT ? bz % nch : 0;
+    const int r0 = by * BM, s0 = bx * BN;
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const float *Vb = V + (long long)b * C * S;
     const int steps = (C + BK - 1) / BK;
@@ -116,65 +138,126 @@ dynfilter_fwd_vec(const float *__restrict__ V, const float *__restrict__ F, floa
 // rounding after each, i.e. it continues the same fmaf chain as the vector kernel.
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 constexpr int MF_ROW = 12;               // BK / 2 = 8 k-pairs per row + padding (16-byte aligned rows)
+// Round 3: the kernel was bound by its global -> LDS staging (two barriers and one exposed LDS round trip per
+// 8 MFMAs: 47 % of the MFMA issue slots at B = 32).  Now a stage is TWO K-steps (32 columns of C, 16 MFMAs per
+// wave), the LDS tiles are double-buffered -- the registers fetched during stage st-1 are written into the
+// other buffer at the top of stage st, the loads of stage st+2 are issued, then the MFMAs of stage st run --
+// and ONE barrier closes the stage.  The per-K-step order of the fmaf chain and the chunk boundaries are those
+// of dynfilter_fwd_vec, so the bits are unchanged (a chunk may end between the two K-steps of a stage; a stage
+// that sticks out of the chunk range is fed zeros: + 0 * 0).
+constexpr int MF_KS = 2;                 // K-steps per stage
 
 template <bool SPLIT>
 __global__ void __launch_bounds__(256)
 dynfilter_fwd_mfma(const float *__restrict__ V, const float *__restrict__ F, float *__restrict__ P,
                    int B, int R, int K, int C, int S, int spc, int nch)
 {
-    __shared__ __attribute__((aligned(16))) float As2[2][BM][MF_ROW];   // [k parity][row][k / 2]
-    __shared__ __attribute__((aligned(16))) float Bs2[2][BN][MF_ROW];   // [k parity][col][k / 2]
-    const int b = SPLIT ? (int)blockIdx.z / nch : (int)blockIdx.z, ch = SPLIT ? (int)blockIdx.z % nch : 0;
-    const int r0 = blockIdx.y * BM, s0 = blockIdx.x * BN;
+    __shared__ __attribute__((aligned(16))) float As2[2][MF_KS][2][BM][MF_ROW];   // [buffer][K-step][k parity][row][k / 2]
+    int bx, by, bz;
+    if (!xcd_tile((S + BN - 1) / BN, (R + BM - 1) / BM, SPLIT ? B * nch : B, bx, by, bz)) return;
+    const int b = SPLIT ? bz / nch : bz, ch = SPLIT ? bz % nch : 0;
+    const int r0 = by * BM, s0 = bx * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;      // this wave's quarter of the tile
     const int l32 = lane & 31, half = lane >> 5;
     const float *Vb = V + (long long)b * C * S;
     const int steps = (C + BK - 1) / BK;
     const int st_lo = SPLIT ? ch * spc : 0, st_hi = SPLIT ? min(steps, (ch + 1) * spc) : steps;
+    const int c_hi = min(C, st_hi * BK);                        // columns of C past the range read as zero
 
-    const int ar = tid >> 2, ac = (tid & 3) * 4;     // A: row ar, k-offset ac..ac+3
-    const int bk = tid >> 4, bc = (tid & 15) * 4;    // B: k-row bk, col bc..bc+3
+    const int ar = tid >> 2, ac = (tid & 3) * 4;     // A: row ar, k-offset ac..ac+3 of a K-step
     const bool a_ok = (r0 + ar) < R;
-    const float *Ap = F + (a_ok ? lbk_row(r0 + ar, b, B, K, C) : 0);
-    const bool b_ok = (s0 + bc) < S;
 
     f32x16_t acc, tot;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc[i] = 0.0f; tot[i] = 0.0f; }
-    float4 av = make_float4(0, 0, 0, 0), bv = make_float4(0, 0, 0, 0);
-    auto fetch = [&](int c0) {
-        av = (a_ok && c0 + ac < C) ? *reinterpret_cast<const float4 *>(Ap + c0 + ac) : make_float4(0, 0, 0, 0);
-        bv = (b_ok && c0 + bk < C) ? *reinterpret_cast<const float4 *>(Vb + (long long)(c0 + bk) * S + s0 + bc)
-                                   : make_float4(0, 0, 0, 0);
-    };
-    if (st_lo < st_hi) fetch(st_lo * BK);
-    int left = spc;
-    for (int st = st_lo; st < st_hi; ++st) {
-        *reinterpret_cast<float2 *>(&As2[0][ar][ac / 2]) = make_float2(av.x, av.z);
-        *reinterpret_cast<float2 *>(&As2[1][ar][ac / 2]) = make_float2(av.y, av.w);
-        Bs2[bk & 1][bc + 0][bk >> 1] = bv.x; Bs2[bk & 1][bc + 1][bk >> 1] = bv.y;
-        Bs2[bk & 1][bc + 2][bk >> 1] = bv.z; Bs2[bk & 1][bc + 3][bk >> 1] = bv.w;
-        __syncthreads();
-        if (st + 1 < st_hi) fetch((st + 1) * BK);
-        const float4 a0 = *reinterpret_cast<const float4 *>(&As2[half][wm + l32][0]);
-        const float4 a1 = *reinterpret_cast<const float4 *>(&As2[half][wm + l32][4]);
-        const float4 b0 = *reinterpret_cast<const float4 *>(&Bs2[half][wn + l32][0]);
-        const float4 b1 = *reinterpret_cast<const float4 *>(&Bs2[half][wn + l32][4]);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, acc, 0, 0, 0);
-        __syncthreads();
-        if (!SPLIT && (--left == 0 || st + 1 == st_hi)) {       // chunk boundary: fold the chunk sum in
+    // Operand fetches are BUFFER loads whose masks live in the descriptor and the offset, not in branches: as
+    // guarded global loads (`ok ? load : 0`) hipcc branched around every load and waited vmcnt(0) right behind it
+    // to merge the two values -- a synchronous "prefetch", one exposed L2 round trip per operand and stage.
+    //   A (the filters): staged through LDS, 16 bytes per lane and K-step.  Its descriptor ends at column c_hi of
+    //   the LAST row of the tile, and a lane past the range of its own row points past the window: zeros.
+    //   B (the features): NOT staged.  The MFMA wants lane (n, k parity) to hold V[c0 + 2 kk + parity][column n]:
+    //   a coalesced row read, so each wave loads its eight scalars per K-step straight into registers (through
+    //   LDS they were transposed with 4-byte writes that hit 8 banks of 64).  The sample's descriptor ends with
+    //   its C rows, so the rows of the last, partial K-step read as zeros; rows past a chunk's end (SPLIT) meet
+    //   zero filter values.  One v_add per load is all the address arithmetic left (the kernel issued 200 VALU
+    //   instructions per 16 MFMAs before: rocprofv3 SQ_INSTS_VALU, profiles/r3_dynfilter.txt).
+    const rsrc_t rF = make_rsrc(F);
+    const rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Vb), 0, (unsigned)((long long)C * S * 4), 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    const unsigned a_off = a_ok ? (unsigned)(lbk_row(r0 + ar, b, B, K, C) * sizeof(float)) + (unsigned)ac * 4u : OOB;
+    const unsigned a_lim = a_ok ? a_off - (unsigned)ac * 4u + (unsigned)c_hi * 4u : 0u;    // first byte past this row's range
+    const bool n_ok = (s0 + wn + l32) < S;
+    const unsigned b_off = n_ok ? (unsigned)((s0 + wn + l32) * sizeof(float)) + (unsigned)half * (unsigned)S * 4u : OOB;
+    const unsigned rowB = (unsigned)S * 4u;
+    // Fetch distance: ONE stage, into the register set the stage before last has finished with (two sets, the
+    // stage loop unrolled by 2 so that the set index is a compile-time constant).  Two stages ahead (three B sets,
+    // loop unrolled by 6) measured SLOWER: 0.1445 vs 0.1326 ms at B = 32, 63.6 vs 78.8 TFLOP/s at B = 64.
+    float4 av[MF_KS];
+    float bb[2][MF_KS][8];                           // B scalars: landing set / working set alternate per stage
+    auto fetch = [&](int c0, auto setc) {            // the MF_KS K-steps starting at column c0, B into set `setc`
+        constexpr int set = decltype(setc)::value;
+        const unsigned ca = a_off + (unsigned)c0 * 4u;
+        const unsigned cbase = b_off + (unsigned)c0 * rowB;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { tot[i] += acc[i]; acc[i] = 0.0f; }
-            left = spc;
+        for (int q = 0; q < MF_KS; ++q) {
+            const unsigned oa = ca + (unsigned)(q * BK) * 4u;
+            av[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rF, oa < a_lim ? oa : OOB, 0, 0));
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+                bb[set][q][kk] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    rV, cbase + (unsigned)(q * BK + 2 * kk) * rowB, 0, 0));
         }
+    };
+    auto stage_to_lds = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < MF_KS; ++q) {
+            *reinterpret_cast<float2 *>(&As2[buf][q][0][ar][ac / 2]) = make_float2(av[q].x, av[q].z);
+            *reinterpret_cast<float2 *>(&As2[buf][q][1][ar][ac / 2]) = make_float2(av[q].y, av[q].w);
+        }
+    };
+    const int nstage = (st_hi - st_lo + MF_KS - 1) / MF_KS;
+    if (nstage > 0) {
+        fetch(st_lo * BK, IC<0>{});
+        stage_to_lds(0);
+        if (nstage > 1) fetch((st_lo + MF_KS) * BK, IC<1>{});
+    }
+    __syncthreads();
+    int left = spc, st = st_lo;
+    // stage sg computes from LDS buffer sg & 1 and B set sg & 1; behind its MFMAs it writes stage sg+1's A (fetched a
+    // stage ago) into the other buffer and fetches stage sg+2 into the set it has just finished with
+    auto stage = [&](int sg, auto setc) {
+        constexpr int set = decltype(setc)::value;
+#pragma unroll
+        for (int q = 0; q < MF_KS; ++q) {
+            if (st < st_hi) {                        // (uniform) the last stage of an odd range has one K-step
+                const float4 a0 = *reinterpret_cast<const float4 *>(&As2[set][q][half][wm + l32][0]);
+                const float4 a1 = *reinterpret_cast<const float4 *>(&As2[set][q][half][wm + l32][4]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bb[set][q][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bb[set][q][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, bb[set][q][2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bb[set][q][3], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, bb[set][q][4], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, bb[set][q][5], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, bb[set][q][6], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, bb[set][q][7], acc, 0, 0, 0);
+                ++st;
+                if (!SPLIT && (--left == 0 || st == st_hi)) {   // chunk boundary: fold the chunk sum in
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { tot[i] += acc[i]; acc[i] = 0.0f; }
+                    left = spc;
+                }
+            }
+        }
+        if (sg + 1 < nstage) {
+            stage_to_lds(set ^ 1);
+            if (sg + 2 < nstage) fetch((st_lo + (sg + 2) * MF_KS) * BK, setc);
+        }
+        __syncthreads();
+    };
+    for (int sg = 0; sg < nstage; sg += 2) {
+        stage(sg, IC<0>{});
+        if (sg + 1 < nstage) stage(sg + 1, IC<1>{});
     }
     // D layout of 32x32x2: register i of lane (n = lane % 32, h = lane / 32) is row 8 * (i / 4) + 4 * h + i % 4
     const int sc = s0 + wn + l32;
@@ -301,10 +384,12 @@ dynfilter_bwd_vec(const float *__restrict__ V, const float *__restrict__ F, cons
 {
     __shared__ float As[BK][BM + PAD];
     __shared__ float Bs[BK][BN + PAD];
-    const int b = blockIdx.z, m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int Md = (MODE == 2) ? C : R, Nd = (MODE == 1) ? C : S, Kd = (MODE == 1) ? S : R;
+    int bx, by, b;
+    if (!xcd_tile((Nd + BN - 1) / BN, (Md + BM - 1) / BM, B, bx, by, b)) return;
+    const int m0 = by * BM, n0 = bx * BN;
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const float *Vb = V + (long long)b * C * S;
-    const int Md = (MODE == 2) ? C : R, Nd = (MODE == 1) ? C : S, Kd = (MODE == 1) ? S : R;
 
     f32x2_t acc2[4][2];
 #pragma unroll
@@ -313,17 +398,24 @@ dynfilter_bwd_vec(const float *__restrict__ V, const float *__restrict__ F, cons
     // MODE 1: lane -> (row tid >> 2, k-offset (tid & 3) * 4) of both operands (k-contiguous)
     // MODE 2: lane -> (k-row tid >> 4, tile offset (tid & 15) * 4) of both operands (tile-contiguous)
     const int rr = (MODE == 1) ? tid >> 2 : tid >> 4, off = (MODE == 1) ? (tid & 3) * 4 : (tid & 15) * 4;
+    // branch-free fetches: buffer loads whose mask is the offset (outside -> past the 2 GiB window -> zeros); as
+    // guarded global loads every fetch was a branch plus an immediate vmcnt(0) (see dynfilter_fwd_mfma)
+    const rsrc_t rV = make_rsrc(Vb), rF = make_rsrc(F), rG = make_rsrc(gP);
+    constexpr unsigned OOB = 0x80000000u;
     const bool a_row_ok = (MODE == 1) ? (m0 + rr) < R : true;
-    const float *Arow = (MODE == 1) ? gP + (a_row_ok ? lbk_row(m0 + rr, b, B, K, S) : 0) : nullptr;
+    const unsigned arow_off = (MODE == 1 && a_row_ok) ? (unsigned)(lbk_row(m0 + rr, b, B, K, S) * sizeof(float)) : 0u;
+    auto ld = [&](rsrc_t r, bool ok, unsigned off) {
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, ok ? off : OOB, 0, 0));
+    };
     auto fetch = [&](int k0) {
-        const float4 z = make_float4(0, 0, 0, 0);
         if (MODE == 1) {
-            av = (a_row_ok && k0 + off < S) ? *reinterpret_cast<const float4 *>(Arow + k0 + off) : z;
-            bv = ((n0 + rr) < C && k0 + off < S) ? *reinterpret_cast<const float4 *>(Vb + (long long)(n0 + rr) * S + k0 + off) : z;
+            av = ld(rG, a_row_ok && k0 + off < S, arow_off + (unsigned)(k0 + off) * 4u);
+            bv = ld(rV, (n0 + rr) < C && k0 + off < S, (unsigned)(((long long)(n0 + rr) * S + k0 + off) * 4));
         } else {
             const int r = k0 + rr;
-            av = (r < R && m0 + off < C) ? *reinterpret_cast<const float4 *>(F + lbk_row(r, b, B, K, C) + m0 + off) : z;
-            bv = (r < R && n0 + off < S) ? *reinterpret_cast<const float4 *>(gP + lbk_row(r, b, B, K, S) + n0 + off) : z;
+            const int rc = r < R ? r : 0;
+            av = ld(rF, r < R && m0 + off < C, (unsigned)((lbk_row(rc, b, B, K, C) + m0 + off) * 4));
+            bv = ld(rG, r < R && n0 + off < S, (unsigned)((lbk_row(rc, b, B, K, S) + n0 + off) * 4));
         }
     };
     fetch(0);
@@ -415,16 +507,19 @@ static int dynfilter_fwd_impl(const char *fn, const float *V, const float *F, fl
     bool split = workspace && nch > 1 && !((uintptr_t)workspace & 15) && (long long)B * nch <= 65535 &&
                  (se ? atoi(se) != 0 : tiles < 4 * NUM_CU);
     const char *me = getenv("DMN_DYNFILTER_MFMA");              // 0: the packed-FMA kernels (A/B runs)
-    const bool mfma = !(me && atoi(me) == 0);
+    // (the matrix-core kernel addresses F through one 2 GiB buffer window)
+    const bool mfma = !(me && atoi(me) == 0) && (long long)L * B * K * C * 4 < 0x7fffffffLL && (long long)C * S * 4 < 0x7fffffffLL;
+    auto xcd_grid = [](long long tiles) { return dim3((unsigned)(((tiles + 7) / 8) * 8)); };
+    if (tiles * (split ? nch : 1) >= (1LL << 30)) return fail(-5, "%s: too many tiles", fn);
     if (split) {
-        dim3 sgrid(grid.x, grid.y, B * nch);
+        dim3 sgrid = xcd_grid(tiles * nch);
         if (mfma) hipLaunchKernelGGL(dynfilter_fwd_mfma<true>, sgrid, dim3(256), 0, s, V, F, workspace, B, R, K, C, S, spc, nch);
         else hipLaunchKernelGGL(dynfilter_fwd_vec<true>, sgrid, dim3(256), 0, s, V, F, workspace, B, R, K, C, S, spc, nch);
         const long long n4 = (long long)B * R * S / 4;
         hipLaunchKernelGGL(dynfilter_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, workspace, P, B, R, K, S, nch);
     } else {
-        if (mfma) hipLaunchKernelGGL(dynfilter_fwd_mfma<false>, grid, dim3(256), 0, s, V, F, P, B, R, K, C, S, spc, nch);
-        else hipLaunchKernelGGL(dynfilter_fwd_vec<false>, grid, dim3(256), 0, s, V, F, P, B, R, K, C, S, spc, nch);
+        if (mfma) hipLaunchKernelGGL(dynfilter_fwd_mfma<false>, xcd_grid(tiles), dim3(256), 0, s, V, F, P, B, R, K, C, S, spc, nch);
+        else hipLaunchKernelGGL(dynfilter_fwd_vec<false>, xcd_grid(tiles), dim3(256), 0, s, V, F, P, B, R, K, C, S, spc, nch);
     }
     return launch_status(fn);
 }
@@ -450,15 +545,16 @@ extern "C" int dmn_dynfilter_bwd(const float *V, const float *F, const float *gP
     hipStream_t s = (hipStream_t)stream;
     const char *ve = getenv("DMN_DYNFILTER_BWD_VEC");
     const bool vec = (C % 4 == 0) && (S % 4 == 0) && !(ve && atoi(ve) == 0) &&
-                     !(((uintptr_t)V | (uintptr_t)F | (uintptr_t)gP | (uintptr_t)gV | (uintptr_t)gF) & 15);
+                     !(((uintptr_t)V | (uintptr_t)F | (uintptr_t)gP | (uintptr_t)gV | (uintptr_t)gF) & 15) &&
+                     (long long)L * B * K * C * 4 < 0x7fffffffLL && (long long)C * S * 4 < 0x7fffffffLL;   // one 2 GiB buffer window per tensor
     if (gF) {
         dim3 grid((C + BN - 1) / BN, (R + BM - 1) / BM, B);
-        if (vec) hipLaunchKernelGGL(dynfilter_bwd_vec<1>, grid, dim3(256), 0, s, V, F, gP, gF, B, R, K, C, S);
+        if (vec) hipLaunchKernelGGL(dynfilter_bwd_vec<1>, dim3((unsigned)((((long long)grid.x * grid.y * B + 7) / 8) * 8)), dim3(256), 0, s, V, F, gP, gF, B, R, K, C, S);
         else hipLaunchKernelGGL(dynfilter_generic<1>, grid, dim3(256), 0, s, V, gP, (const float *)nullptr, gF, B, R, K, C, S);
     }
     if (gV) {
         dim3 grid((S + BN - 1) / BN, (C + BM - 1) / BM, B);
-        if (vec) hipLaunchKernelGGL(dynfilter_bwd_vec<2>, grid, dim3(256), 0, s, V, F, gP, gV, B, R, K, C, S);
+        if (vec) hipLaunchKernelGGL(dynfilter_bwd_vec<2>, dim3((unsigned)((((long long)grid.x * grid.y * B + 7) / 8) * 8)), dim3(256), 0, s, V, F, gP, gV, B, R, K, C, S);
         else hipLaunchKernelGGL(dynfilter_generic<2>, grid, dim3(256), 0, s, V, F, gP, gV, B, R, K, C, S);
     }
     return launch_status("dmn_dynfilter_bwd");
