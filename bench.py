@@ -116,7 +116,7 @@ class LaunchTimer(object):
             return "dynfilter_fwd", 4 * B * (C * S + L * K * C + L * K * S)
         if name == "dmn_mix_sru_fwd":
             B, L, K, S, d = args[9:14]
-            return ("mix+sru_fwd fused k=4 T=%d cols=%d (issue-bound)" % (S * L, B * d),
+            return ("mix+sru_fwd fused k=4 T=%d cols=%d" % (S * L, B * d),
                     4 * B * (S * 4 * d + L * 4 * d + L * K * S + S * L * d))
         if name == "dmn_mix_bcast_add":
             B, L, K, S, M = args[6:11]
@@ -202,15 +202,36 @@ class LaunchTimer(object):
             return 2 * 2 * B * L * K * C * S
         return 0
 
+    @staticmethod
+    def issue_bound_ms(name, args):
+        """Kernels bound by one wave's in-order instruction issue, not by HBM or a FLOP peak: the time their
+        instruction stream needs at the documented issue rates, or 0.
+        dmn_mix_sru_fwd (matrix-core pair kernel, K = 10, L = 20): per block of 32 steps the OUTPUT wave issues
+        20 fp32 MFMAs (64 cycles each in the pipe), 32 v_permlane32_swap (8), 16 ds_read_b128 + 32 v_pk_add_f32 for
+        the tile start values (8 / 4), the scan's 3 transcendentals (quarter rate: 16) + 6 full-rate VALU (4) per
+        step, ~150 cycles of operand hand-over: 4246 cycles.  Every 64-column window is one wave pair, all pairs run
+        at once while there are at most 1024 waves (one per SIMD), in ceil(waves / 1024) shares of a SIMD beyond."""
+        if name == "dmn_mix_sru_fwd":
+            B, L, K, S, d = args[9:14]
+            if K != 10 or L != 20:
+                return 0.0
+            blocks = (S * L + 31) // 32
+            cycles = 20 * 64 + 32 * 8 + (16 * 8 + 32 * 4) + 32 * (3 * 16 + 6 * 4) + 150
+            waves = 2 * B * ((d + 15 + 63) // 64)
+            share = max((waves + 1023) // 1024, 1)
+            return share * blocks * cycles / 2.4e9 * 1e3
+        return 0.0
+
     def summary(self):
         agg = {}
         for name, args, a, b in self.records:
             label, nbytes = self.describe(name, args)
-            e = agg.setdefault(label, {"calls": 0, "ms": 0.0, "bytes": 0, "flops": 0})
+            e = agg.setdefault(label, {"calls": 0, "ms": 0.0, "bytes": 0, "flops": 0, "issue_ms": 0.0})
             e["calls"] += 1
             e["ms"] += a.elapsed_time(b)
             e["bytes"] += nbytes
             e["flops"] += self.flops(name, args)
+            e["issue_ms"] += self.issue_bound_ms(name, args)
         out = []
         for label, e in agg.items():
             avg_ms = e["ms"] / e["calls"]
@@ -219,7 +240,11 @@ class LaunchTimer(object):
                         "total_ms": round(e["ms"], 3),
                         "algorithmic_bytes_per_launch": e["bytes"] // e["calls"],
                         "achieved_GBs": round(gbs, 1), "frac_of_8TBs": round(gbs / HBM_PEAK_GBS, 4)})
-            if e["flops"]:
+            if e["issue_ms"]:
+                out[-1].update({"bound": "wave issue (one in-order instruction stream per SIMD; neither HBM nor a FLOP peak)",
+                                "issue_bound_ms": round(e["issue_ms"] / e["calls"], 4),
+                                "frac_of_bound": round(e["issue_ms"] / e["ms"], 4)})
+            elif e["flops"]:
                 tf = e["flops"] / (e["ms"] * 1e-3) / 1e12
                 out[-1].update({"achieved_TFLOPs": round(tf, 1), "frac_of_157TF_fp32": round(tf / 157.0, 4),
                                 "bound": "fp32 issue (above the HBM ridge)"})
