@@ -253,9 +253,9 @@ class LaunchTimer(object):
 
 
 def measured_traffic(kernel_label):
-    """HBM bytes per launch from the committed PMC passes (profiles/traffic_r1.json; separate
+    """HBM bytes per launch from the committed PMC passes (profiles/traffic_r3.json, else r2 / r1; separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 FETCH x2 correction) or None."""
-    for name in ("traffic_r2.json", "traffic_r1.json"):
+    for name in ("traffic_r3.json", "traffic_r2.json", "traffic_r1.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 table = json.load(f)

@@ -311,7 +311,7 @@ sru_bwd_cols(const float *__restrict__ U, const float *__restrict__ x,
 }
 
 // grad_bias[g*d + j] = sum over b (ascending) of part[g*ncols + b*d + j], g < ngates
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64)
 sru_bwd_bias_reduce(const float *__restrict__ part, float *__restrict__ grad_bias, int B, int d, int ngates)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -319,7 +319,15 @@ sru_bwd_bias_reduce(const float *__restrict__ part, float *__restrict__ grad_bia
     const int g = i / d, j = i - g * d;
     const float *p = part + (size_t)g * B * d + j;
     float acc = 0.0f;
-    for (int b = 0; b < B; ++b) acc += p[(size_t)b * d];
+    int b = 0;
+    for (; b + 8 <= B; b += 8) {                     // eight loads in flight, added in sample order
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = p[(size_t)(b + q) * d];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc += v[q];
+    }
+    for (; b < B; ++b) acc += p[(size_t)b * d];
     grad_bias[i] = acc;
 }
 
@@ -372,7 +380,7 @@ extern "C" int dmn_sru_state_bwd(const float *U2, const float *bias, const float
     else DMN_SB(16);
 #undef DMN_SB
     if (bias_partials)
-        hipLaunchKernelGGL(sru_bwd_bias_reduce, dim3((d + 255) / 256), dim3(256), 0, s, bias_partials, grad_bias_f, B, d, 1);
+        hipLaunchKernelGGL(sru_bwd_bias_reduce, dim3((d + 63) / 64), dim3(64), 0, s, bias_partials, grad_bias_f, B, d, 1);
     return launch_status(fn);
 }
 
@@ -423,6 +431,6 @@ extern "C" int dmn_sru_bwd(const float *U, const float *x, const float *bias, co
     else        DMN_BWD_K(4);
 #undef DMN_BWD_K
     if (bias_partials)
-        hipLaunchKernelGGL(sru_bwd_bias_reduce, dim3((2 * d + 255) / 256), dim3(256), 0, s, bias_partials, grad_bias, B, d, 2);
+        hipLaunchKernelGGL(sru_bwd_bias_reduce, dim3((2 * d + 63) / 64), dim3(64), 0, s, bias_partials, grad_bias, B, d, 2);
     return launch_status(fn);
 }

@@ -94,6 +94,8 @@ int dmn_sru_fwd_image(const float *U, const float *x, const float *bias, const f
  *   All calls on one GPU share that GPU's array: calls that OVERLAP on one GPU (two streams, two
  *   threads) race on it -- serialise them, or use dmn_sru_fwd_scan with separate workspaces.
  *   Nothing in the array has to start at zero (every carry is written before it is read).
+ *   The FIRST call on a device resolves the array's device address (hipGetSymbolAddress, under a mutex):
+ *   call once per device BEFORE a stream capture; every later call only launches kernels.
  */
 #define DMN_SCAN_SCRATCH_FLOATS (1 << 20)
 int dmn_sru_fwd_scan_noalloc(const float *U, const float *x, const float *bias, const float *c0,
