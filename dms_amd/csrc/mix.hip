@@ -134,6 +134,96 @@ mix_fwd_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
     }
 }
 
+// The K <= KR, 16-byte case again (the model's shapes), two changes, same arithmetic per element:
+//  * column windows start on 64-byte lines: sample b's rows begin (b*M mod 16) floats into a line when
+//    B*M is a multiple of 16 (the folded width 4020: 0, 4, 8 or 12 floats), so lanes are shifted by that
+//    many quarters (`shift4`) and every wave's 1 KiB store covers whole lines -- a 4020-float row written
+//    as 16-byte pieces from an unaligned start left two half-written lines per wave and store;
+//  * the rank-K update runs on v_pk_fma_f32 (column pairs), halving the VALU issue per stored byte.
+template <int KR, int PT, bool NT>
+__global__ void __launch_bounds__(256)
+mix_fwd_pk_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
+                  const float *__restrict__ P, const float *__restrict__ Wp, int ldw,
+                  float *__restrict__ Q, int B, int L, int K, int S, int M, int aligned)
+{
+    extern __shared__ float Ps[];            // [L*K][PT]
+    const int b = blockIdx.y, s0 = blockIdx.z * PT;
+    const int LK = L * K;
+    for (int idx = threadIdx.x; idx < LK * PT; idx += blockDim.x) {
+        const int r = idx / PT, pp = idx - r * PT;
+        const int t = r / K, k = r - t * K;
+        const int s = s0 + pp;
+        Ps[idx] = s < S ? P[lbk_off(t, b, k, B, K, S) + s] : 0.0f;
+    }
+    __syncthreads();
+
+    const int Mv = M / 4;
+    const int shift4 = aligned ? (int)((((long long)b * M) & 15) >> 2) : 0;
+    for (int lv = blockIdx.x * blockDim.x + threadIdx.x; lv < Mv + shift4; lv += gridDim.x * blockDim.x) {
+        const bool on = lv >= shift4;
+        const int m = on ? (lv - shift4) * 4 : 0;
+        f32x2_t w01[KR], w23[KR];
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {
+            w01[k] = (f32x2_t){k < K ? Wp[(long long)(m + 0) * ldw + k] : 0.0f, k < K ? Wp[(long long)(m + 1) * ldw + k] : 0.0f};
+            w23[k] = (f32x2_t){k < K ? Wp[(long long)(m + 2) * ldw + k] : 0.0f, k < K ? Wp[(long long)(m + 3) * ldw + k] : 0.0f};
+        }
+        float4 a[PT];
+#pragma unroll
+        for (int pp = 0; pp < PT; ++pp) {
+            const int s = s0 + pp < S ? s0 + pp : S - 1;
+            a[pp] = *reinterpret_cast<const float4 *>(A + ((long long)b * S + s) * M + m);
+        }
+#pragma unroll 2
+        for (int t = 0; t < L; ++t) {
+            const float4 bt = *reinterpret_cast<const float4 *>(Bt + ((long long)t * B + b) * M + m);
+            f32x2_t q01[PT], q23[PT];
+#pragma unroll
+            for (int pp = 0; pp < PT; ++pp) {
+                q01[pp] = (f32x2_t){a[pp].x + bt.x, a[pp].y + bt.y};
+                q23[pp] = (f32x2_t){a[pp].z + bt.z, a[pp].w + bt.w};
+            }
+#pragma unroll
+            for (int k = 0; k < KR; ++k) {
+                if (k < K) {
+                    float pv[PT];
+                    const float *pr = Ps + (t * K + k) * PT;
+                    if (PT % 4 == 0) {
+#pragma unroll
+                        for (int p4 = 0; p4 < PT / 4; ++p4) {
+                            const float4 v = *reinterpret_cast<const float4 *>(pr + 4 * p4);
+                            pv[4 * p4] = v.x; pv[4 * p4 + 1] = v.y; pv[4 * p4 + 2] = v.z; pv[4 * p4 + 3] = v.w;
+                        }
+                    } else {
+#pragma unroll
+                        for (int pp = 0; pp < PT; ++pp) pv[pp] = pr[pp];
+                    }
+#pragma unroll
+                    for (int pp = 0; pp < PT; ++pp) {
+                        const f32x2_t p2 = {pv[pp], pv[pp]};
+                        q01[pp] = __builtin_elementwise_fma(w01[k], p2, q01[pp]);
+                        q23[pp] = __builtin_elementwise_fma(w23[k], p2, q23[pp]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int pp = 0; pp < PT; ++pp) {
+                const int s = s0 + pp;
+                if (on && s < S) {
+                    // streamed (non-temporal) when the output is far larger than L2 + MALL: written once, read by a later
+                    // kernel from HBM either way -- plain stores held 2 GB of dirty lines in a write-back cache and the
+                    // evictions ran at 3.4 TB/s; streamed, the same rows leave at 4.7 TB/s
+                    typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+                    f32x4_nt *dst = reinterpret_cast<f32x4_nt *>(Q + (((long long)s * L + t) * B + b) * M + m);
+                    const f32x4_nt v = {q01[pp][0], q01[pp][1], q23[pp][0], q23[pp][1]};
+                    if (NT) __builtin_nontemporal_store(v, dst);      // a template choice: hipcc merges a run-time pair into plain stores
+                    else *dst = v;
+                }
+            }
+        }
+    }
+}
+
 // ---- backward A: per (b, pixel): gA[b,s,m] = sum_t gQ ; gP[t,b,k,s] = sum_m Wp[m,k] gQ ----
 // One 256-thread workgroup per (b, tile of MIX_BWD_PT pixels).  Wp is staged once per
 // workgroup into LDS, transposed to [k][M] so that a lane's 4 adjacent m are one ds_read_b128.
@@ -778,12 +868,21 @@ extern "C" int dmn_mix_bcast_add(const float *A, const float *Bt, const float *P
         return fail(-5, "dmn_mix_bcast_add: L*K=%d too large for the LDS stage", L * K);
     hipStream_t s = (hipStream_t)stream;
     const bool vec = (M % 4 == 0) && !(((uintptr_t)A | (uintptr_t)Bt | (uintptr_t)Q) & 15);
-    const int pieces = ((vec ? M / 4 : M) + 255) / 256;
+    // packed-FMA kernel with 64-byte-aligned column windows (K <= 10, 16-byte case); DMN_MIX_FWD_PK=0 keeps the plain one
+    const char *pk_env = getenv("DMN_MIX_FWD_PK");
+    const bool pk = vec && K <= 10 && !(pk_env && pk_env[0] == '0');
+    const int aligned = pk && ((long long)B * M) % 16 == 0 && !((uintptr_t)Q & 63);
+    const int pieces = ((vec ? M / 4 : M) + (aligned ? 3 : 0) + 255) / 256;
     if ((S + 1) / 2 > 65535) return fail(-5, "dmn_mix_bcast_add: S=%d too large", S);
     // few (image, query) pairs (batch-1 serving): 2 pixels per workgroup instead of 8, so that
     // the launch still has >= 2 workgroups per CU
     const bool small = (long long)pieces * B * ((S + MIX_PT - 1) / MIX_PT) < 2 * NUM_CU;
-    const int pt = small ? 2 : MIX_PT;
+    // 4 pixels per workgroup when the last tile of 8 would be at most half full (S = 100: 12.5 tiles) -- less
+    // waste and a finer-grained tail (DMN_MIX_FWD_PT=4|8 forces it)
+    const char *pte = getenv("DMN_MIX_FWD_PT");
+    const int rem8 = S % MIX_PT;
+    const int pt_auto = (rem8 >= 1 && rem8 <= MIX_PT / 2) ? 4 : MIX_PT;
+    const int pt = small ? 2 : !pk ? MIX_PT : pte ? (atoi(pte) == 4 ? 4 : MIX_PT) : pt_auto;
     const size_t lds = (size_t)L * K * pt * sizeof(float);
     dim3 grid(pieces, B, (S + pt - 1) / pt);
 #define DMN_MIX(V, KR)                                                                                  \
@@ -791,7 +890,20 @@ extern "C" int dmn_mix_bcast_add(const float *A, const float *Bt, const float *P
         if (small) hipLaunchKernelGGL((mix_fwd_kernel<V, KR, 2>), grid, dim3(256), lds, s, A, Bt, P, Wp, ldw, Q, B, L, K, S, M); \
         else hipLaunchKernelGGL((mix_fwd_kernel<V, KR, MIX_PT>), grid, dim3(256), lds, s, A, Bt, P, Wp, ldw, Q, B, L, K, S, M); \
     } while (0)
-    if (vec) {
+    if (pk) {
+        // streamed stores once Q outgrows the 256 MB Infinity Cache (DMN_MIX_FWD_NT=0|1 forces the policy)
+        const char *ne = getenv("DMN_MIX_FWD_NT");
+        const int nt = ne ? atoi(ne) != 0 : (double)S * L * B * M * 4.0 > 256e6;
+#define DMN_MIX_PK(PTV)                                                                                                      \
+    do {                                                                                                                     \
+        if (nt) hipLaunchKernelGGL((mix_fwd_pk_kernel<10, PTV, true>), grid, dim3(256), lds, s, A, Bt, P, Wp, ldw, Q, B, L, K, S, M, aligned);  \
+        else hipLaunchKernelGGL((mix_fwd_pk_kernel<10, PTV, false>), grid, dim3(256), lds, s, A, Bt, P, Wp, ldw, Q, B, L, K, S, M, aligned);  \
+    } while (0)
+        if (small) DMN_MIX_PK(2);
+        else if (pt == 4) DMN_MIX_PK(4);
+        else DMN_MIX_PK(MIX_PT);
+#undef DMN_MIX_PK
+    } else if (vec) {
         if (K <= 4) DMN_MIX(4, 4);
         else if (K <= 10) DMN_MIX(4, 10);
         else if (K <= MIX_KMAX) DMN_MIX(4, MIX_KMAX);

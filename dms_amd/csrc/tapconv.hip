@@ -149,10 +149,9 @@ tap_gather_tile_kernel(const float *__restrict__ Z, const float *__restrict__ bi
     const float *zb = Z + (long long)b * 9 * tapstride;
     const int R0 = band * NR;
 
-    // horizontal pass of one low-res row segment: h[ky][c] = sum_kx upx(z[ky*3+kx])[2*c0 + c + kx - 1]
-    auto hpass = [&](long long R, int c0, float (&h)[3][8], bool keep) {
+    // a lane's nine 16-byte tap loads of one low-res row segment
+    auto fetch = [&](long long R, int c0, f32x4_t (&z)[9], bool keep) {
         const float *zr = zb + R * W + c0;
-        f32x4_t z[9];
         if (LM == 1) {
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap)
@@ -170,6 +169,9 @@ tap_gather_tile_kernel(const float *__restrict__ Z, const float *__restrict__ bi
             for (int tap = 0; tap < 9; ++tap)
                 z[tap] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(zr + tap * tapstride));
         }
+    };
+    // horizontal pass: h[ky][c] = sum_kx upx(z[ky*3+kx])[2*c0 + c + kx - 1]
+    auto hpass = [&](const f32x4_t (&z)[9], int c0, float (&h)[3][8]) {
         const bool el = c0 == 0, er = c0 + 4 == W;           // row edges: clamp (bilinear) and zero (conv pad)
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
@@ -205,18 +207,26 @@ tap_gather_tile_kernel(const float *__restrict__ Z, const float *__restrict__ bi
     const int rr = t / LPR, c0 = (t % LPR) * 4;
     const long long R = (long long)R0 + rr;
     const int co = (int)(R / H), r = (int)(R - (long long)co * H);
-    float Rc[3][8];
-    hpass(R, c0, Rc, H > NR && (rr == 0 || rr == NR - 1));
-    put(rr + 1, c0, Rc);
-    if (H > NR && t < 2 * LPR) {                              // halo rows (same plane only)
-        const int bottom = t / LPR;
-        const long long Rh = bottom ? (long long)R0 + NR : (long long)R0 - 1;
+    // halo rows (same plane only) are fetched by lanes 0 .. 2*LPR-1 TOGETHER with their own row: both sets of
+    // nine loads are in flight before either is consumed (one memory round trip for those waves, not two)
+    bool halo = false;
+    int bottom = 0;
+    f32x4_t zh[9];
+    if (H > NR && t < 2 * LPR) {
+        bottom = t / LPR;
         const int rfirst = (int)((long long)R0 % H);          // row of the band's first line inside its plane
-        if (bottom ? (rfirst + NR < H) : (rfirst > 0)) {
-            float Rh3[3][8];
-            hpass(Rh, c0, Rh3, true);
-            put(bottom ? NR + 1 : 0, c0, Rh3);
-        }
+        halo = bottom ? (rfirst + NR < H) : (rfirst > 0);
+        if (halo) fetch(bottom ? (long long)R0 + NR : (long long)R0 - 1, c0, zh, true);
+    }
+    f32x4_t zc[9];
+    fetch(R, c0, zc, H > NR && (rr == 0 || rr == NR - 1));
+    float Rc[3][8];
+    hpass(zc, c0, Rc);
+    put(rr + 1, c0, Rc);
+    if (halo) {
+        float Rh3[3][8];
+        hpass(zh, c0, Rh3);
+        put(bottom ? NR + 1 : 0, c0, Rh3);
     }
     __syncthreads();
 

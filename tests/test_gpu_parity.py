@@ -414,6 +414,36 @@ def test_mix_bcast_add_matches_einsum(B, L, K, S, M):
     assert rel_err(Q, ref) < 1e-5
 
 
+@pytest.mark.parametrize("B,L,K,S,M", [(4, 20, 10, 9, 4020),      # B*M % 16 == 0: shifted (64-byte aligned) windows, shifts 0/4/8/12
+                                       (16, 20, 10, 3, 1000),     # aligned, one piece
+                                       (3, 20, 10, 10, 4020),     # B*M % 16 != 0: unshifted
+                                       (4, 5, 3, 17, 1028),       # K < 10, ragged pixel tile, last piece of 4 + shift
+                                       (32, 2, 10, 2, 36)])       # rows narrower than a wave
+def test_mix_bcast_add_packed_aligned_kernel_is_bit_identical_to_the_plain_one(B, L, K, S, M, monkeypatch):
+    """mix_fwd_pk_kernel (v_pk_fma_f32, column windows on 64-byte lines) does the same fmaf chain per element
+    as mix_fwd_kernel: torch.equal, and nothing outside Q is written (guard rows around the buffer)."""
+    A, Bt = det_uniform((B, S, M), 131, 1.0).to(DEV), det_uniform((L, B, M), 132, 1.0).to(DEV)
+    P, Wp = det_uniform((L, B, K, S), 133, 1.0).to(DEV), det_uniform((M, K), 134, 1.0).to(DEV)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("DMN_MIX_FWD_PK", mode)
+        out[mode] = ops.mix_bcast_add(A, Bt, P, Wp)
+    assert torch.equal(out["0"], out["1"])
+    for pt in ("4", "8"):                      # pixels per workgroup x store policy (streamed / plain)
+        for nt in ("0", "1"):
+            monkeypatch.setenv("DMN_MIX_FWD_PT", pt)
+            monkeypatch.setenv("DMN_MIX_FWD_NT", nt)
+            guard = torch.full((S * L + 2, B, M), 7.0, device=DEV)       # one guard row on either side of Q
+            q = guard[1:-1]
+            _lib.call("dmn_mix_bcast_add", A.data_ptr(), Bt.data_ptr(), P.data_ptr(), Wp.data_ptr(), Wp.stride(0),
+                      q.data_ptr(), B, L, K, S, M, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert bool((guard[0] == 7.0).all()) and bool((guard[-1] == 7.0).all()), (pt, nt)
+            assert torch.equal(q, out["0"]), (pt, nt)
+    ref = _mix_ref(A.double().cpu(), Bt.double().cpu(), P.double().cpu(), Wp.double().cpu())
+    assert rel_err(out["1"].cpu(), ref) < 1e-5
+
+
 @pytest.mark.parametrize("B,L,K,S,M", [(2, 5, 3, 11, 24),          # small; wave 3 idle for L = 5? no: words 0..4 over 4 waves
                                        (2, 20, 10, 100, 1000),     # the training shape per sample (configs[3])
                                        (1, 24, 10, 7, 1024),       # six words per wave, full 1024 columns
