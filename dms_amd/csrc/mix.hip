@@ -571,20 +571,24 @@ mix_bwd_word2_kernel(const float *__restrict__ gQ, const float *__restrict__ P,
 // order, and stores in between can only make the wait stricter).  A wave reads only its own row slots, so the
 // wait alone orders them (MI355X_MICROARCH.md item 7); P is read by every wave, two barriers after its wait.
 // Requires K <= 10, L <= 20, M % 4 == 0, 16-byte aligned gQ / gA / gBt.
-constexpr int MIX_ONE_COLS = 512;
+constexpr int MIX_ONE_COLS = 256;          // columns per wave quartet; a workgroup has HALVES quartets (one or two)
 constexpr int MIX_ONE_NW = 5;            // words per wave: L <= 20
-constexpr int MIX_ONE_RUN = 16;          // pixels of gP gathered in LDS before they are written (64-byte runs)
 #ifndef DMN_MIX_ONE_PROBE
 #define DMN_MIX_ONE_PROBE 0      // timing probes (tools/probe_mix_one.sh): 1 no butterfly, 2 no combine/stores, 3 no gw FMAs, 4 no gQ loads
 #endif
 
+// HALVES = 2: 512 threads, 512 columns, one 158 KB workgroup per CU (its eight waves wait for memory together).
+// HALVES = 1: 256 threads, 256 columns, 79 KB: TWO independent workgroups per CU, so that one computes while the
+// other waits at its per-pixel wait / barrier (twice the gP partials: + 41 MB written and read back).
+template <int HALVES>
 struct MixOneLds {
-    float G[3][8][MIX_ONE_NW][256];      // [pixel slot][wave][word][64 lanes x 4 columns]            120 KB
-    float dummy[256];                    // landing zone of loads nobody reads (words past L, waves 4-7's P piece)  1 KB
-    float Ps[4][256];                    // P[t, b, k, s] of a pixel as [t][k] (first 200 used)           4 KB
-    float ga[2][4][MIX_ONE_COLS];        //                                                              16 KB
-    float red[2][4][2][64];              //                                                               4 KB
-    float gp[4 * MIX_ONE_NW * MIX_BWD2_K][MIX_ONE_RUN];   // a run of pixels of this block's gP share  12.5 KB
+    static constexpr int RUN = HALVES == 2 ? 16 : 8;   // pixels of gP gathered in LDS before they are written (64 / 32-byte runs)
+    float G[3][4 * HALVES][MIX_ONE_NW][256];   // [pixel slot][wave][word][64 lanes x 4 columns]       120 / 60 KB
+    float dummy[256];                          // landing zone of loads nobody reads (words past L, waves 4-7's P piece)  1 KB
+    float Ps[4][256];                          // P[t, b, k, s] of a pixel as [t][k] (first 200 used)      4 KB
+    float ga[2][4][MIX_ONE_COLS * HALVES];     //                                                         16 / 8 KB
+    float red[HALVES == 2 ? 2 * 4 * 2 * 64 : 1];   // [buf][wq][batch][lane], second quartet -> first      4 KB / -
+    float gp[4 * MIX_ONE_NW * MIX_BWD2_K][RUN];    // a run of pixels of this block's gP share          12.5 / 6.25 KB
 };
 
 __device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(unsigned long long)p; }
@@ -601,19 +605,33 @@ __device__ __forceinline__ void dma_b32(unsigned lds_base, i32x4 srd, unsigned v
                  :: "s"(lds_base), "v"(voff), "s"(srd), "s"(soff) : "memory", "m0");
 }
 
-__global__ void __launch_bounds__(512)
+template <int HALVES>
+__global__ void __launch_bounds__(256 * HALVES)
 mix_bwd_one_kernel(const float *__restrict__ gQ, const float *__restrict__ P, const float *__restrict__ Wp, int ldw,
                    float *__restrict__ gA, float *__restrict__ gBt, float *__restrict__ gPpart,
-                   float *__restrict__ gWpart, int B, int L, int K, int S, int M)
+                   float *__restrict__ gWpart, int B, int L, int K, int S, int M, int ncb, int xcd_map)
 {
     constexpr int NW = MIX_ONE_NW, KR = MIX_BWD2_K, KP = KR / 2;
+    constexpr int NT = 256 * HALVES, COLS = MIX_ONE_COLS * HALVES, RUN = MixOneLds<HALVES>::RUN;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    MixOneLds &sm = *reinterpret_cast<MixOneLds *>(lds_raw);
-    const int cb = blockIdx.x, b = blockIdx.y;
+    MixOneLds<HALVES> &sm = *reinterpret_cast<MixOneLds<HALVES> *>(lds_raw);
+    // 1-D grid.  Workgroups are dealt to the 8 XCDs round-robin; with xcd_map (B % 8 == 0) an XCD takes ALL column
+    // blocks of its samples, consecutively: the workgroups resident on an XCD then read whole 16 KB rows between
+    // them (a few samples x 20 words per pixel step) instead of one 2 KB piece of every sample's rows -- 8x fewer
+    // distinct pages per XCD and step for the address translation to keep up with
+    int cb, b;
+    if (xcd_map) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        b = (j / ncb) * 8 + xcd;
+        cb = j - (j / ncb) * ncb;
+    } else {
+        b = blockIdx.x / ncb;
+        cb = blockIdx.x - b * ncb;
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform for the compiler too (SGPR asm operands)
-    const int wq = wave & 3, half = wave >> 2;
-    const int m = cb * MIX_ONE_COLS + half * 256 + lane * 4;
+    const int wq = wave & 3, half = HALVES == 2 ? wave >> 2 : 0;
+    const int m = cb * COLS + half * 256 + lane * 4;
     const bool mok = m < M;                                // M % 4 == 0: all four columns or none
 
     f32x2_t w2[4][KP], gw2[4][KP];
@@ -633,7 +651,7 @@ mix_bwd_one_kernel(const float *__restrict__ gQ, const float *__restrict__ P, co
     for (int tt = 0; tt < NW; ++tt) gbt2[tt][0] = gbt2[tt][1] = (f32x2_t){0.0f, 0.0f};
 
     // zero the row slots once: the slots of words past L are never written again (their loads land in `dummy`)
-    for (int i = tid; i < 3 * 8 * NW * 256 / 4; i += 512)
+    for (int i = tid; i < 3 * 4 * HALVES * NW * 256 / 4; i += NT)
         reinterpret_cast<float4 *>(&sm.G[0][0][0][0])[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     __syncthreads();
 
@@ -764,7 +782,7 @@ mix_bwd_one_kernel(const float *__restrict__ gQ, const float *__restrict__ P, co
         asm volatile("" ::"v"(tot[0]), "v"(tot[1]), "v"(ga2[0]), "v"(ga2[1]));
         continue;
 #endif
-        if (half == 1) { sm.red[buf][wq][0][lane] = tot[0]; sm.red[buf][wq][1][lane] = tot[1]; }
+        if (HALVES == 2 && half == 1) { sm.red[((buf * 4 + wq) * 2 + 0) * 64 + lane] = tot[0]; sm.red[((buf * 4 + wq) * 2 + 1) * 64 + lane] = tot[1]; }
         *reinterpret_cast<float4 *>(&sm.ga[buf][wq][half * 256 + lane * 4]) = make_float4(ga2[0].x, ga2[0].y, ga2[1].x, ga2[1].y);
         __syncthreads();
         // this block's share of gP: gathered over MIX_ONE_RUN pixels in LDS, written as 64-byte runs (one
@@ -775,31 +793,31 @@ mix_bwd_one_kernel(const float *__restrict__ gQ, const float *__restrict__ P, co
                 const int idx = lane >> 1, bt = idx / KR, k = idx - bt * KR;
                 const int tt = (batch ? NB1 : 0) + bt, t = wq + 4 * tt;
                 if (bt < (batch ? NB2 : NB1) && t < 4 * NW)
-                    sm.gp[t * KR + k][s & (MIX_ONE_RUN - 1)] = tot[batch] + sm.red[buf][wq][batch][lane];
+                    sm.gp[t * KR + k][s & (RUN - 1)] = HALVES == 2 ? tot[batch] + sm.red[((buf * 4 + wq) * 2 + batch) * 64 + lane] : tot[batch];
             }
         }
-        if ((s & (MIX_ONE_RUN - 1)) == MIX_ONE_RUN - 1 || s == S - 1) {     // uniform
+        if ((s & (RUN - 1)) == RUN - 1 || s == S - 1) {     // uniform
             __syncthreads();
-            const int s0 = s & ~(MIX_ONE_RUN - 1), n = s - s0 + 1;
+            const int s0 = s & ~(RUN - 1), n = s - s0 + 1;
             float *gpo = gPpart + (long long)cb * L * B * K * S;
             if ((S & 3) == 0 && (n & 3) == 0) {
-                for (int i = tid; i < 4 * NW * KR * (MIX_ONE_RUN / 4); i += 512) {
-                    const int row = i / (MIX_ONE_RUN / 4), q = i - row * (MIX_ONE_RUN / 4);
+                for (int i = tid; i < 4 * NW * KR * (RUN / 4); i += NT) {
+                    const int row = i / (RUN / 4), q = i - row * (RUN / 4);
                     const int t = row / KR, k = row - t * KR;
                     if (t < L && k < K && 4 * q < n)
                         *reinterpret_cast<float4 *>(gpo + lbk_off(t, b, k, B, K, S) + s0 + 4 * q) =
                             *reinterpret_cast<const float4 *>(&sm.gp[row][4 * q]);
                 }
             } else {
-                for (int i = tid; i < 4 * NW * KR * MIX_ONE_RUN; i += 512) {
-                    const int row = i / MIX_ONE_RUN, q = i - row * MIX_ONE_RUN;
+                for (int i = tid; i < 4 * NW * KR * RUN; i += NT) {
+                    const int row = i / RUN, q = i - row * RUN;
                     const int t = row / KR, k = row - t * KR;
                     if (t < L && k < K && q < n) gpo[lbk_off(t, b, k, B, K, S) + s0 + q] = sm.gp[row][q];
                 }
             }
         }
         {
-            const int mcol = cb * MIX_ONE_COLS + tid;
+            const int mcol = cb * COLS + tid;
             if (mcol < M)
                 gA[((long long)b * S + s) * M + mcol] = (sm.ga[buf][0][tid] + sm.ga[buf][1][tid])
                                                         + (sm.ga[buf][2][tid] + sm.ga[buf][3][tid]);
@@ -925,8 +943,17 @@ static bool mix_bwd_one_pass(int B, int L, int K, int M)
     if (!(K <= MIX_BWD2_K && nw <= MIX_ONE_NW && M % 4 == 0)) return false;
     const char *e = getenv("DMN_MIX_BWD_ONE");
     if (e) return atoi(e) != 0;
-    const long long wgs = (long long)B * ((M + MIX_ONE_COLS - 1) / MIX_ONE_COLS);
+    const long long wgs = (long long)B * ((M + 2 * MIX_ONE_COLS - 1) / (2 * MIX_ONE_COLS));
     return wgs >= NUM_CU / 2;
+}
+// wave quartets per workgroup: 1 (two independent 256-column workgroups per CU) unless DMN_MIX_ONE_HALVES=2
+static int mix_one_halves(int B, int M)
+{
+    const char *e = getenv("DMN_MIX_ONE_HALVES");
+    if (e) return atoi(e) == 2 ? 2 : 1;
+    // 512-column workgroups (one per CU) once they fill the chip -- 0.57 vs 0.64 ms at M = 4020, B = 64; below that the
+    // 256-column ones give twice the workgroups (M = 1000, B = 64: 0.19 vs 0.25 ms)
+    return (long long)B * ((M + 2 * MIX_ONE_COLS - 1) / (2 * MIX_ONE_COLS)) >= NUM_CU ? 2 : 1;
 }
 }  // namespace dmn
 
@@ -941,7 +968,7 @@ extern "C" long long dmn_mix_bwd_workspace_floats(int B, int L, int K, int S, in
 {
     if (B <= 0 || L <= 0 || K <= 0 || S <= 0 || M <= 0) return -1;
     if (!mix_bwd_one_pass(B, L, K, M)) return 0;
-    return (long long)((M + MIX_ONE_COLS - 1) / MIX_ONE_COLS) * L * B * K * S;
+    return (long long)((M + MIX_ONE_COLS - 1) / MIX_ONE_COLS) * L * B * K * S;    // one gP share per 256 columns (enough for either kernel)
 }
 
 extern "C" int dmn_mix_bcast_add_bwd(const float *gQ, const float *P, const float *Wp, int ldw,
@@ -959,16 +986,24 @@ extern "C" int dmn_mix_bcast_add_bwd(const float *gQ, const float *P, const floa
         if (((uintptr_t)gA | (uintptr_t)gBt | (uintptr_t)gWp_part) & 15)
             return fail(-5, "dmn_mix_bcast_add_bwd: gA, gBt and gWp_part must be 16-byte aligned");
         if (!workspace) return fail(-1, "dmn_mix_bcast_add_bwd: this shape needs a workspace of dmn_mix_bwd_workspace_floats() floats");
-        const int ncb = (M + MIX_ONE_COLS - 1) / MIX_ONE_COLS;
-        dim3 grid(ncb, B);
-        // 156 KB of the CU's 160 KB LDS: opt in (cheap; per call, so that every device of the process gets it)
-        {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mix_bwd_one_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MixOneLds));
-            if (e != hipSuccess) return fail((int)e, "dmn_mix_bcast_add_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        }
-        hipLaunchKernelGGL(mix_bwd_one_kernel, grid, dim3(512), sizeof(MixOneLds), s, gQ, P, Wp, ldw, gA, gBt, workspace,
-                           gWp_part, B, L, K, S, M);
+        const int halves = mix_one_halves(B, M);
+        const int ncb = (M + halves * MIX_ONE_COLS - 1) / (halves * MIX_ONE_COLS);
+        if ((long long)ncb * B >= (1LL << 31)) return fail(-5, "dmn_mix_bcast_add_bwd: grid too large");
+        dim3 grid((unsigned)(ncb * B));
+        const char *xe = getenv("DMN_MIX_ONE_XCD");
+        const int xcd_map = (B % 8 == 0) && !(xe && atoi(xe) == 0);
+        // 79 / 158 KB of the CU's 160 KB LDS: opt in (cheap; per call, so that every device of the process gets it)
+#define DMN_MIX_ONE(HV)                                                                                                  \
+    do {                                                                                                                 \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mix_bwd_one_kernel<HV>),                       \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MixOneLds<HV>));     \
+        if (e != hipSuccess) return fail((int)e, "dmn_mix_bcast_add_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); \
+        hipLaunchKernelGGL(mix_bwd_one_kernel<HV>, grid, dim3(256 * HV), sizeof(MixOneLds<HV>), s, gQ, P, Wp, ldw, gA, gBt, \
+                           workspace, gWp_part, B, L, K, S, M, ncb, xcd_map);                                            \
+    } while (0)
+        if (halves == 2) DMN_MIX_ONE(2);
+        else DMN_MIX_ONE(1);
+#undef DMN_MIX_ONE
         const long long n = (long long)L * B * K * S;
         hipLaunchKernelGGL(mix_bwd_sum_parts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, workspace, gP, n, ncb);
         return launch_status("dmn_mix_bcast_add_bwd");

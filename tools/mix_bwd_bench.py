@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """dmn_mix_bcast_add_bwd at the training shape (configs[3]: 320 px, B = 64): ms and achieved GB/s of the
-one-pass kernel (round 3) vs the two-pass kernels (round 2), at the unfolded (M = 1000) and folded
-(M = 4020) row widths.  GB/s counts gQ ONCE (the algorithmic traffic)."""
+one-pass kernels (round 3: 256- and 512-column workgroups, with and without the XCD-aware block order) vs the
+two-pass kernels (round 2), at the unfolded (M = 1000) and folded (M = 4020) row widths.
+GB/s counts gQ ONCE (the algorithmic traffic)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -16,10 +17,14 @@ gA = torch.empty((B, S, M), device=dev); gBt = torch.empty((L, B, M), device=dev
 gP = torch.empty_like(P)
 st = torch.cuda.current_stream().cuda_stream
 nbytes = 4 * (gQ.numel() + gA.numel() + gBt.numel() + gP.numel() + B * M * K + P.numel())
-
 REPS = int(os.environ.get("MIXBENCH_REPS", "20"))
-for mode in os.environ.get("MIXBENCH_MODES", "01"):
-    os.environ["DMN_MIX_BWD_ONE"] = mode
+NAMES = {"0": "two passes", "1": "ONE pass, 256-column workgroups", "2": "ONE pass, 512-column workgroups"}
+
+
+def bench(mode, xcd):
+    os.environ["DMN_MIX_BWD_ONE"] = "0" if mode == "0" else "1"
+    os.environ["DMN_MIX_ONE_HALVES"] = mode if mode in "12" else "1"
+    os.environ["DMN_MIX_ONE_XCD"] = xcd
     parts = _lib.query("dmn_mix_bwd_parts", B, L, K, S, M)
     nws = _lib.query("dmn_mix_bwd_workspace_floats", B, L, K, S, M)
     gW = torch.empty((parts, M, K), device=dev)
@@ -38,6 +43,11 @@ for mode in os.environ.get("MIXBENCH_MODES", "01"):
         run()
     b.record(); torch.cuda.synchronize()
     ms = a.elapsed_time(b) / REPS
-    print("mix_bcast_add_bwd (+ the caller's sum over %d gWp slabs) B=%d L=%d K=%d S=%d M=%d %s: %.4f ms  %.0f GB/s = %.3f of 8 TB/s "
-          "(algorithmic %.0f MB, gQ once)" % (parts, B, L, K, S, M, "ONE pass" if mode == "1" else "two passes", ms,
+    print("mix_bcast_add_bwd (+ the caller's sum over %d gWp slabs) B=%d L=%d K=%d S=%d M=%d %s%s: %.4f ms  %.0f GB/s = %.3f of 8 TB/s "
+          "(algorithmic %.0f MB, gQ once)" % (parts, B, L, K, S, M, NAMES[mode], "" if mode == "0" else " xcd_map=" + xcd, ms,
                                              nbytes / ms / 1e6, nbytes / ms / 1e6 / 8000, nbytes / 1e6), flush=True)
+
+
+for mode in os.environ.get("MIXBENCH_MODES", "012"):
+    for xcd in (("1",) if mode == "0" else ("0", "1")):
+        bench(mode, xcd)
