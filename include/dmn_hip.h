@@ -235,9 +235,10 @@ int dmn_mix_sru_fwd(const float *A, const float *Bt, const float *Pt, const floa
  *   slabs, parts = dmn_mix_bwd_parts(B, L, K, S, M).
  * Two implementations, chosen by shape (same choice in the two query functions):
  *   - ONE pass over gQ (K <= 10, L <= 20, M % 4 == 0 and B * ceil(M / 512) >= 128 workgroups): a workgroup
- *     owns 512 columns of one sample and walks all its pixels; parts = 4*B; `workspace` holds
- *     dmn_mix_bwd_workspace_floats() floats (per-column-block shares of gP, added in block order:
- *     deterministic).  gQ, gA, gBt, gWp_part 16-byte aligned.
+ *     owns 512 columns of one sample (256 when 512-column workgroups could not fill the chip) and walks all its
+ *     pixels; parts = 4*B; `workspace` holds dmn_mix_bwd_workspace_floats() floats (one share of gP per 256
+ *     columns -- enough for either workgroup shape -- added in block order: deterministic).
+ *     gQ, gA, gBt, gWp_part 16-byte aligned.
  *   - two passes (pixel pass gA / gP, word pass gBt / gWp) otherwise: parts = L*B, workspace unused (may be
  *     NULL); K <= 16, M % 4 == 0; rows wider than 1024 floats need K <= 10 and L <= 24.
  */
