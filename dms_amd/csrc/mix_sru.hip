@@ -122,7 +122,15 @@ mix_sru_fwd_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
     DMN_MS_WAIT(0);
     int buf = 0;
     for (int s = 0; s < S; ++s) {
-        const float4 ac = make_float4(a_nx.x, a_nx.y, a_nx.z, a_nx.w);
+        // This pixel's A leaves the prefetch registers through asm moves: as a plain copy hipcc kept `ac` in the old
+        // registers, gave the next fetch new ones and moved them back at the loop's end -- IN FRONT of the counted wait
+        // below, i.e. while that load could still be in flight (K = 10, L != 20 variants; found by
+        // tools/check_asm_waits.py once it followed this kernel's control flow).  volatile asm statements keep their
+        // order, so a_nx now lives in one register set for the whole loop.
+        float4 ac;
+        asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
+                     : "=&v"(ac.x), "=&v"(ac.y), "=&v"(ac.z), "=&v"(ac.w)
+                     : "v"(a_nx.x), "v"(a_nx.y), "v"(a_nx.z), "v"(a_nx.w));
         if constexpr (LX > 0 && KX > 0) {
             float hold[PREG];                                 // this pixel's P while the next one loads
 #pragma unroll
@@ -157,8 +165,7 @@ mix_sru_fwd_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
         for (int k = 0; k < KR; ++k) pn[k] = (KX > 0 || k < K) ? pl[k] : 0.0f;
         float4 btn = bt_lds[threadIdx.x];
         float *hs = hp + (long long)s * L * hstride;
-#pragma unroll 2
-        for (int t = 0; t < L; ++t) {
+        auto word = [&](int t) {
             float pv[KR];
 #pragma unroll
             for (int k = 0; k < KR; ++k) pv[k] = pn[k];
@@ -183,7 +190,16 @@ mix_sru_fwd_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
             cur = __builtin_fmaf(cur - q[0], f, q[0]);
             const float hv = __builtin_fmaf(act_fwd<ACT>(cur) - q[3], r, q[3]);
             __builtin_nontemporal_store(hv, hs + (long long)t * hstride);
+        };
+        // the first WB words as a loop of their own with a compile-time trip count: the wait below counts on WB
+        // stores behind the fetch, and this way the code itself says so (L >= WB is the host's choice of WB;
+        // tools/check_asm_waits.py follows counted loops, not a promise about a run-time L)
+        if constexpr (WB > 0) {
+#pragma unroll 2
+            for (int t = 0; t < WB; ++t) word(t);
         }
+#pragma unroll 2
+        for (int t = WB; t < L; ++t) word(t);
         }
         // the L stores above are younger than the fetch: leave (at most) WB <= L of them outstanding
         DMN_MS_WAIT(WB);

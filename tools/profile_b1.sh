@@ -1,7 +1,7 @@
 #!/bin/bash
 set -e
 R=${GRAFT_REPO_ROOT:-$PWD}
-O=$R/gpurun_out/prof_r2
+O=$R/gpurun_out/prof_r3
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 export PYTHONPATH=$R
