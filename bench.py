@@ -220,6 +220,15 @@ class LaunchTimer(object):
             waves = 2 * B * ((d + 15 + 63) // 64)
             share = max((waves + 1023) // 1024, 1)
             return share * blocks * cycles / 2.4e9 * 1e3
+        if name == "dmn_mix_bcast_add_bwd":
+            # one-pass kernel (K <= 10, L <= 20, 512-column workgroups, one per CU = two waves per SIMD): 437 VALU
+            # instructions per wave and pixel (rocprofv3 SQ_INSTS_VALU, profiles/r3_mix_bwd_one.txt) at ~4.4 cycles
+            # (packed fp32 FMAs, DPP / permlane exchanges); its HBM floor is lower (2.2 GB: 0.28 ms)
+            B, L, K, S, M = args[9:14]
+            wgs = B * ((M + 511) // 512)
+            if K > 10 or L > 20 or M % 4 or wgs < 256:
+                return 0.0
+            return ((wgs + 255) // 256) * S * 2 * 437 * 4.4 / 2.4e9 * 1e3
         return 0.0
 
     def summary(self):

@@ -147,18 +147,21 @@ constexpr int MF_ROW = 12;               // BK / 2 = 8 k-pairs per row + padding
 // that sticks out of the chunk range is fed zeros: + 0 * 0).
 constexpr int MF_KS = 2;                 // K-steps per stage
 
-template <bool SPLIT>
-__global__ void __launch_bounds__(256)
+// BMT = 64: four waves, a 64 x 64 tile.  BMT = 32: two waves (128 threads), a 32 x 64 tile -- R = 200 filter rows are
+// 6.25 x 32: seven 32-row tiles issue 224 rows of MFMA work where four 64-row tiles issue 256, and a sample has 28
+// workgroups instead of 16.
+template <bool SPLIT, int BMT>
+__global__ void __launch_bounds__(4 * BMT)
 dynfilter_fwd_mfma(const float *__restrict__ V, const float *__restrict__ F, float *__restrict__ P,
                    int B, int R, int K, int C, int S, int spc, int nch)
 {
-    __shared__ __attribute__((aligned(16))) float As2[2][MF_KS][2][BM][MF_ROW];   // [buffer][K-step][k parity][row][k / 2]
+    __shared__ __attribute__((aligned(16))) float As2[2][MF_KS][2][BMT][MF_ROW];   // [buffer][K-step][k parity][row][k / 2]
     int bx, by, bz;
-    if (!xcd_tile((S + BN - 1) / BN, (R + BM - 1) / BM, SPLIT ? B * nch : B, bx, by, bz)) return;
+    if (!xcd_tile((S + BN - 1) / BN, (R + BMT - 1) / BMT, SPLIT ? B * nch : B, bx, by, bz)) return;
     const int b = SPLIT ? bz / nch : bz, ch = SPLIT ? bz % nch : 0;
-    const int r0 = by * BM, s0 = bx * BN;
+    const int r0 = by * BMT, s0 = bx * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;      // this wave's quarter of the tile
+    const int wm = BMT == 64 ? (wave >> 1) * 32 : 0, wn = BMT == 64 ? (wave & 1) * 32 : wave * 32;   // this wave's 32 x 32 part
     const int l32 = lane & 31, half = lane >> 5;
     const float *Vb = V + (long long)b * C * S;
     const int steps = (C + BK - 1) / BK;
@@ -501,24 +504,31 @@ static int dynfilter_fwd_impl(const char *fn, const float *V, const float *F, fl
     }
     int spc, nch;
     df_chunks(C, &spc, &nch);
-    // one workgroup per (tile, chunk) while whole tiles would leave CUs idle (measured: tools/dynfilter_bench.py)
-    const char *se = getenv("DMN_DYNFILTER_SPLIT");
-    const long long tiles = (long long)grid.x * grid.y * B;
-    bool split = workspace && nch > 1 && !((uintptr_t)workspace & 15) && (long long)B * nch <= 65535 &&
-                 (se ? atoi(se) != 0 : tiles < 4 * NUM_CU);
     const char *me = getenv("DMN_DYNFILTER_MFMA");              // 0: the packed-FMA kernels (A/B runs)
     // (the matrix-core kernel addresses F through one 2 GiB buffer window)
     const bool mfma = !(me && atoi(me) == 0) && (long long)L * B * K * C * 4 < 0x7fffffffLL && (long long)C * S * 4 < 0x7fffffffLL;
+    // matrix-core kernel: 32-row tiles when they pad R less than 64-row ones (R = 200: 224 vs 256 rows of MFMA work, 28
+    // workgroups per sample instead of 16: 63 -> 71 TFLOP/s at B = 32, 75 -> 83 at B = 64; DMN_DYNFILTER_BM=64|32 forces)
+    const char *be = getenv("DMN_DYNFILTER_BM");
+    const int bmt = !mfma ? 64 : be ? (atoi(be) == 32 ? 32 : 64) : (((R + 31) / 32) * 32 < ((R + 63) / 64) * 64 ? 32 : 64);
+    // one workgroup per (tile, chunk) while whole tiles would leave CUs idle (measured: tools/dynfilter_bench.py;
+    // 64-row tiles: below 4 workgroups per CU, 32-row tiles (two waves each): below 3)
+    const char *se = getenv("DMN_DYNFILTER_SPLIT");
+    const long long tiles = (long long)grid.x * ((R + bmt - 1) / bmt) * B;
+    bool split = workspace && nch > 1 && !((uintptr_t)workspace & 15) && (long long)B * nch <= 65535 &&
+                 (se ? atoi(se) != 0 : tiles < (bmt == 32 ? 3 : 4) * NUM_CU);
     auto xcd_grid = [](long long tiles) { return dim3((unsigned)(((tiles + 7) / 8) * 8)); };
     if (tiles * (split ? nch : 1) >= (1LL << 30)) return fail(-5, "%s: too many tiles", fn);
     if (split) {
         dim3 sgrid = xcd_grid(tiles * nch);
-        if (mfma) hipLaunchKernelGGL(dynfilter_fwd_mfma<true>, sgrid, dim3(256), 0, s, V, F, workspace, B, R, K, C, S, spc, nch);
+        if (mfma && bmt == 32) hipLaunchKernelGGL((dynfilter_fwd_mfma<true, 32>), sgrid, dim3(128), 0, s, V, F, workspace, B, R, K, C, S, spc, nch);
+        else if (mfma) hipLaunchKernelGGL((dynfilter_fwd_mfma<true, 64>), sgrid, dim3(256), 0, s, V, F, workspace, B, R, K, C, S, spc, nch);
         else hipLaunchKernelGGL(dynfilter_fwd_vec<true>, sgrid, dim3(256), 0, s, V, F, workspace, B, R, K, C, S, spc, nch);
         const long long n4 = (long long)B * R * S / 4;
         hipLaunchKernelGGL(dynfilter_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, workspace, P, B, R, K, S, nch);
     } else {
-        if (mfma) hipLaunchKernelGGL(dynfilter_fwd_mfma<false>, xcd_grid(tiles), dim3(256), 0, s, V, F, P, B, R, K, C, S, spc, nch);
+        if (mfma && bmt == 32) hipLaunchKernelGGL((dynfilter_fwd_mfma<false, 32>), xcd_grid(tiles), dim3(128), 0, s, V, F, P, B, R, K, C, S, spc, nch);
+        else if (mfma) hipLaunchKernelGGL((dynfilter_fwd_mfma<false, 64>), xcd_grid(tiles), dim3(256), 0, s, V, F, P, B, R, K, C, S, spc, nch);
         else hipLaunchKernelGGL(dynfilter_fwd_vec<false>, xcd_grid(tiles), dim3(256), 0, s, V, F, P, B, R, K, C, S, spc, nch);
     }
     return launch_status(fn);

@@ -297,11 +297,24 @@ tap_project_kernel(const float *__restrict__ x, const float *__restrict__ feat,
             } else {
                 v[0] = src[(long long)c * HW];
             }
+            if (VEC == 4) {
+                // pixel pairs on v_pk_fma_f32 (the weight is one scalar, broadcast to both halves): 18 instead of 36
+                // VALU instructions per 16 bytes loaded; the same fmaf per element
 #pragma unroll
-            for (int r = 0; r < 9; ++r) {
-                const float wv = w[r * C + c0 + c];
+                for (int r = 0; r < 9; ++r) {
+                    const float wv = w[r * C + c0 + c];
+                    const f32x2_t w2 = {wv, wv};
+                    const f32x2_t a01 = __builtin_elementwise_fma(w2, (f32x2_t){v[0], v[1]}, (f32x2_t){acc[r][0], acc[r][1]});
+                    const f32x2_t a23 = __builtin_elementwise_fma(w2, (f32x2_t){v[2], v[VEC - 1]}, (f32x2_t){acc[r][2], acc[r][VEC - 1]});
+                    acc[r][0] = a01.x; acc[r][1] = a01.y; acc[r][2] = a23.x; acc[r][VEC - 1] = a23.y;
+                }
+            } else {
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) acc[r][e] = __builtin_fmaf(wv, v[e], acc[r][e]);
+                for (int r = 0; r < 9; ++r) {
+                    const float wv = w[r * C + c0 + c];
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[r][e] = __builtin_fmaf(wv, v[e], acc[r][e]);
+                }
             }
         }
     }
