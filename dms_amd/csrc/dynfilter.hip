@@ -511,12 +511,14 @@ static int dynfilter_fwd_impl(const char *fn, const float *V, const float *F, fl
     // workgroups per sample instead of 16: 63 -> 71 TFLOP/s at B = 32, 75 -> 83 at B = 64; DMN_DYNFILTER_BM=64|32 forces)
     const char *be = getenv("DMN_DYNFILTER_BM");
     const int bmt = !mfma ? 64 : be ? (atoi(be) == 32 ? 32 : 64) : (((R + 31) / 32) * 32 < ((R + 63) / 64) * 64 ? 32 : 64);
-    // one workgroup per (tile, chunk) while whole tiles would leave CUs idle (measured: tools/dynfilter_bench.py;
-    // 64-row tiles: below 4 workgroups per CU, 32-row tiles (two waves each): below 3)
+    // one workgroup per (tile, chunk) below 4 64 x 64 tiles per CU.  Measured with COLD operands (tools/dynfilter_cold.py: a
+    // 1 GB fill between calls, as inside the step): B = 32: whole 0.176 / split 0.157 ms, B = 64: 0.232 / 0.231 ms.  The
+    // repeat-the-same-call microbench keeps the 157 MB of operands in the Infinity Cache and prefers whole tiles at B = 32
+    // (0.123 vs 0.129 ms) -- inside the step that choice ran 0.153 ms against 0.137 ms for split.
     const char *se = getenv("DMN_DYNFILTER_SPLIT");
     const long long tiles = (long long)grid.x * ((R + bmt - 1) / bmt) * B;
     bool split = workspace && nch > 1 && !((uintptr_t)workspace & 15) && (long long)B * nch <= 65535 &&
-                 (se ? atoi(se) != 0 : tiles < (bmt == 32 ? 3 : 4) * NUM_CU);
+                 (se ? atoi(se) != 0 : (long long)grid.x * grid.y * B < 4 * NUM_CU);
     auto xcd_grid = [](long long tiles) { return dim3((unsigned)(((tiles + 7) / 8) * 8)); };
     if (tiles * (split ? nch : 1) >= (1LL << 30)) return fail(-5, "%s: too many tiles", fn);
     if (split) {

@@ -8,6 +8,7 @@ python tools/trace_steps.py $O/bench/bench_kernel_trace.csv 40 > profiles/r3_ben
 cp $O/bench_under_rocprof.json profiles/r3_bench_under_rocprof.json
 head -60 $O/train/train_kernel_stats.csv > profiles/r3_train320_kernel_stats_top60.csv
 cp $O/train_under_rocprof.json profiles/r3_train320_under_rocprof.json
+python tools/trace_steps.py $O/train/train_kernel_trace.csv 60 | cut -c1-200 > profiles/r3_train320_steady_state_per_step.txt
 cp $O/r3k/r3k_kernel_stats.csv profiles/r3_kernels_kernel_stats.csv
 cp $O/sck/sck_kernel_stats.csv profiles/r3_scan_kernel_stats.csv
 for p in r3 r2 sc; do
