@@ -275,6 +275,135 @@ dynfilter_fwd_mfma(const float *__restrict__ V, const float *__restrict__ F, flo
     }
 }
 
+// ---- forward on the matrix cores, operands through an LDS-DMA ring (round 3) -------------------------------------
+// Same chunk order and bits as dynfilter_fwd_mfma (tested with torch.equal against every other variant).  There a workgroup has ONE stage of operands
+// in flight (registers), so with cold operands the library runs it as (tile, chunk) workgroups plus a reduction
+// pass to get enough loads in flight.  Here both operands go global -> LDS directly (buffer_load_dwordx4 .. lds: no
+// registers), D - 1 = 3 stages (96 columns of C) ahead of the MFMAs, retired with one counted s_waitcnt vmcnt per stage
+// and one barrier; every wave issues the same IPW loads per stage (stages past the end are fetched out of bounds:
+// zeros into a free slot), so the count is a constant.
+// LDS layout of a stage, chosen so that both the DMA writes (lane i -> byte 16 i of a 1 KiB piece) and the MFMA operand
+// reads are conflict-free:
+//   A: [K-step][row][4 chunks of 4 k], chunk c of row r at position c ^ ((r >> 2) & 3);
+//   B: [32 k][16 chunks of 4 columns], chunk c of row k at position c ^ (8 * (k & 1)).
+
+__device__ __forceinline__ void df_dma_b128(unsigned lds_base, i32x4 srd, unsigned voff, unsigned soff)
+{
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds_base), "v"(voff), "s"(srd), "s"(soff) : "memory", "m0");
+}
+
+template <int BMT, int D>
+__global__ void __launch_bounds__(4 * BMT)
+dynfilter_fwd_dma(const float *__restrict__ V, const float *__restrict__ F, float *__restrict__ P,
+                  int B, int R, int K, int C, int S, int spc)
+{
+    constexpr int NWV = BMT / 16;                       // waves per workgroup: 2 or 4
+    constexpr int A_INS = BMT / 8, B_INS = 8;           // 1 KiB DMA pieces per stage (A: BMT rows x 32 k, B: 32 k x 64 columns)
+    constexpr int IPW = (A_INS + B_INS) / NWV;          // pieces per wave and stage: 6 or 4
+    constexpr int STAGE = (A_INS + B_INS) * 1024;       // bytes
+    extern __shared__ __attribute__((aligned(16))) unsigned char df_lds[];     // [D][STAGE]
+    int bx, by, bz;
+    if (!xcd_tile((S + BN - 1) / BN, (R + BMT - 1) / BMT, B, bx, by, bz)) return;
+    const int b = bz, r0 = by * BMT, s0 = bx * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = BMT == 64 ? (wave >> 1) * 32 : 0, wn = BMT == 64 ? (wave & 1) * 32 : wave * 32;
+    const int l32 = lane & 31, half = lane >> 5;
+    const int steps = (C + BK - 1) / BK;
+    const int nstage = (steps + 1) / 2;
+    constexpr unsigned OOB = 0x80000000u;
+
+    // this wave's pieces: i = wave + NWV * n; per-lane source offsets are loop-invariant, the stage moves in soffset
+    i32x4 srdF = make_srd(F);
+    srdF.z = (int)((long long)R * B * C * 4);            // the last rows' look-ahead past the tensor reads zeros, not memory
+    i32x4 srdV = make_srd(V + (long long)b * C * S);
+    srdV.z = (int)((long long)C * S * 4);                // rows past C read as zeros
+    constexpr int NA = A_INS / NWV;                      // a wave's first NA pieces are A's (i = wave + NWV n < A_INS), the rest B's
+    unsigned voff[IPW];
+#pragma unroll
+    for (int n = 0; n < IPW; ++n) {
+        const int i = wave + NWV * n;                    // wave-uniform
+        if (n < NA) {
+            const int slot = 64 * i + lane, q = slot / (BMT * 4), rem = slot - q * (BMT * 4);
+            const int row = rem >> 2, cp = rem & 3, c = cp ^ ((row >> 2) & 3);
+            voff[n] = (r0 + row) < R ? (unsigned)(lbk_row(r0 + row, b, B, K, C) * sizeof(float)) + (unsigned)(q * 16 + c * 4) * 4u : OOB;
+        } else {
+            const int slot = 64 * (i - A_INS) + lane, k = slot >> 4, cp = slot & 15, c = cp ^ (8 * (k & 1));
+            voff[n] = (s0 + c * 4) < S ? (unsigned)(k * S + s0 + c * 4) * 4u : OOB;
+        }
+    }
+    const unsigned lds0 = (unsigned)(unsigned long long)df_lds;
+    auto issue = [&](int st) {                           // stage st -> ring slot st % D (st >= nstage: zeros)
+        const bool on = st < nstage;
+        const unsigned base = lds0 + (unsigned)(st % D) * STAGE;
+        const unsigned sA = on ? (unsigned)st * 32u * 4u : 0u, sB = on ? (unsigned)st * 32u * (unsigned)S * 4u : 0u;
+#pragma unroll
+        for (int n = 0; n < IPW; ++n) {
+            const int i = wave + NWV * n;
+            if (n < NA) df_dma_b128(base + (unsigned)i * 1024u, srdF, on ? voff[n] : OOB, sA);
+            else df_dma_b128(base + (unsigned)i * 1024u, srdV, on ? voff[n] : OOB, sB);
+        }
+    };
+#pragma unroll
+    for (int st = 0; st < D - 1; ++st) issue(st);
+
+    // MFMA operand addresses (bytes inside a stage)
+    const int arow = wm + l32;
+    unsigned aoff[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) aoff[c] = (unsigned)((arow * 4 + (c ^ ((arow >> 2) & 3))) * 16);
+    const int n = wn + l32;
+    const unsigned boff = (unsigned)(A_INS * 1024 + half * 256 + ((((n >> 2) ^ (8 * half)) * 4 + (n & 3)) * 4));
+
+    f32x16_t acc, tot;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc[i] = 0.0f; tot[i] = 0.0f; }
+    int left = spc, stp = 0;
+    for (int st = 0; st < nstage; ++st) {
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(IPW * (D - 2)) : "memory");   // this wave's pieces of stage st have landed
+        __syncthreads();                                 // everyone's have; everyone is done with stage st - 1
+        issue(st + D - 1);                               // into the slot of stage st - 1
+        const unsigned char *sb = df_lds + (st % D) * STAGE;
+        const bool up = half != 0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (stp < steps) {                           // (uniform) C's last stage may hold one K-step
+                float4 a[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) a[c] = *reinterpret_cast<const float4 *>(sb + q * (BMT * 64) + aoff[c]);
+                float bv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bv[j] = *reinterpret_cast<const float *>(sb + boff + (q * 16 + 2 * j) * 256);
+                // k = 2 j + half: the lower half-wave takes elements x / z of a chunk, the upper one y / w (v_cndmask; an
+                // array indexed by `half` went to scratch memory, whose loads hipcc waits for with vmcnt(0)).
+                // (Reading both K-steps' operands up front measured slower: 0.126 vs 0.118 ms at B = 32, cold.)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float e0 = up ? a[c].y : a[c].x, e1 = up ? a[c].w : a[c].z;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(e0, bv[2 * c], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(e1, bv[2 * c + 1], acc, 0, 0, 0);
+                }
+                ++stp;
+                if (--left == 0 || stp == steps) {       // chunk boundary: fold the chunk sum in (dynfilter_fwd_vec's order)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { tot[i] += acc[i]; acc[i] = 0.0f; }
+                    left = spc;
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the look-ahead pieces past the end
+    const int sc = s0 + wn + l32;
+    if (sc < S) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = r0 + wm + 8 * (i / 4) + 4 * half + (i % 4);
+            if (r < R) P[lbk_row(r, b, B, K, S) + sc] = tot[i];
+        }
+    }
+}
+
 // P[t,b,k,s] = sum over chunks (in chunk order, starting from +0) of ws[chunk][b][r][s]
 __global__ void __launch_bounds__(256)
 dynfilter_reduce(const float *__restrict__ ws, float *__restrict__ P, int B, int R, int K, int S, int nch)
@@ -521,6 +650,22 @@ static int dynfilter_fwd_impl(const char *fn, const float *V, const float *F, fl
                  (se ? atoi(se) != 0 : (long long)grid.x * grid.y * B < 4 * NUM_CU);
     auto xcd_grid = [](long long tiles) { return dim3((unsigned)(((tiles + 7) / 8) * 8)); };
     if (tiles * (split ? nch : 1) >= (1LL << 30)) return fail(-5, "%s: too many tiles", fn);
+    // operands through an LDS-DMA ring, whole contraction per 64 x 64 tile, no workspace / reduction pass: from one tile per
+    // CU up to 8 (cold operands, tools/dynfilter_cold.py: B = 16 0.076 vs 0.084 ms, B = 32 0.118 vs 0.153, B = 64 0.226 vs
+    // 0.229, training shape B = 64, S = 100 0.121 vs 0.165; below that the (tile, chunk) split wins, above it 32-row whole
+    // tiles do: B = 128 0.430 vs 0.441).  DMN_DYNFILTER_DMA=0|1 forces it off / on.
+    const char *de = getenv("DMN_DYNFILTER_DMA");
+    const long long tiles64 = (long long)grid.x * grid.y * B;
+    const bool dma_ok = mfma && (long long)C * S * 4 + 64LL * S * 4 < 0x7fffffffLL && tiles64 < (1LL << 30);
+    if (dma_ok && (de ? atoi(de) == 1 : (tiles64 >= NUM_CU && tiles64 < 8 * NUM_CU))) {
+        constexpr int D = 4;
+        const int ldsb = D * (64 / 8 + 8) * 1024;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(dynfilter_fwd_dma<64, D>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
+        if (e != hipSuccess) return fail((int)e, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
+        hipLaunchKernelGGL((dynfilter_fwd_dma<64, D>), xcd_grid(tiles64), dim3(256), ldsb, s, V, F, P, B, R, K, C, S, spc);
+        return launch_status(fn);
+    }
     if (split) {
         dim3 sgrid = xcd_grid(tiles * nch);
         if (mfma && bmt == 32) hipLaunchKernelGGL((dynfilter_fwd_mfma<true, 32>), sgrid, dim3(128), 0, s, V, F, workspace, B, R, K, C, S, spc, nch);

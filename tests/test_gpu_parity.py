@@ -343,7 +343,8 @@ def test_dynfilter_matches_per_word_conv2d(B, L, K, C, S):
 
 
 @pytest.mark.parametrize("B,L,K,C,S", [(1, 20, 10, 2696, 256), (2, 20, 10, 2696, 100), (3, 5, 3, 40, 12),
-                                       (1, 2, 2, 16, 4), (2, 7, 9, 1000, 64), (5, 20, 10, 264, 256)])
+                                       (1, 2, 2, 16, 4), (2, 7, 9, 1000, 64), (5, 20, 10, 264, 256), (16, 20, 10, 72, 256),
+                                       (2, 13, 10, 2696, 68)])
 def test_dynfilter_split_contraction_is_bit_identical_to_the_whole_tile_kernel(B, L, K, C, S, monkeypatch):
     """One workgroup per (tile, chunk of C) + reduction (few samples) must give the SAME bits as one
     workgroup per tile (the chunk order of the summation is fixed), so that a sample's filter responses
@@ -352,6 +353,7 @@ def test_dynfilter_split_contraction_is_bit_identical_to_the_whole_tile_kernel(B
     Fi = torch.sigmoid(det_uniform((L, B, K, C), 97, 2.0)).to(DEV)
     ref = torch.einsum("tbkc,bcs->tbks", Fi.double().cpu(), V.double().cpu())
     res = {}
+    monkeypatch.setenv("DMN_DYNFILTER_DMA", "0")               # (the LDS-DMA ring kernel has its own pass below)
     for mfma in ("1", "0"):                                   # matrix-core kernel / packed-FMA kernel
         monkeypatch.setenv("DMN_DYNFILTER_MFMA", mfma)
         monkeypatch.setenv("DMN_DYNFILTER_SPLIT", "1")
@@ -367,6 +369,20 @@ def test_dynfilter_split_contraction_is_bit_identical_to_the_whole_tile_kernel(B
     # fp32 MFMA continues the same k-ordered fmaf chain: the two kernels agree bit for bit
     assert torch.equal(res["1"], res["0"])
     whole = res["1"]
+    # ... and so does the kernel that streams both operands through an LDS-DMA ring (ragged rows / columns / C included:
+    # rows past R and columns past S are fetched out of bounds, a last K-step past C multiplies zero feature rows)
+    monkeypatch.setenv("DMN_DYNFILTER_DMA", "1")
+    for bm in ("64", "32"):
+        monkeypatch.setenv("DMN_DYNFILTER_BM", bm)
+        guard = torch.full((L + 2, B, K, S), 7.0, device=DEV)
+        rc = _lib.call("dmn_dynfilter_fwd", V.data_ptr(), Fi.data_ptr(), guard[1:-1].data_ptr(), B, L, K, C, S,
+                       torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(guard[1:-1], whole), bm
+        assert bool((guard[0] == 7.0).all()) and bool((guard[-1] == 7.0).all())
+    monkeypatch.delenv("DMN_DYNFILTER_BM")
+    monkeypatch.delenv("DMN_DYNFILTER_DMA")
+    assert torch.equal(ops.dynfilter(V, Fi), whole)            # whatever the library picks by itself
     # a sample alone == the same sample inside the batch, bit for bit
     if B > 1:
         alone = ops.dynfilter(V[1:2].contiguous(), Fi[:, 1:2].contiguous())

@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 counter passes over dmn_dynfilter_fwd at B = 32, 512 px (matrix-core kernel, whole tiles).
+# rocprofv3 counter passes over dmn_dynfilter_fwd at B = 32, 512 px (matrix-core kernel, LDS-DMA ring kernel).
 export TMPDIR=/tmp
 out=$PWD/gpurun_out/pmc_dynfilter
 mkdir -p $out
@@ -8,7 +8,7 @@ import os, sys
 sys.path.insert(0, os.getcwd())
 import torch
 from dms_amd import ops
-os.environ["DMN_DYNFILTER_SPLIT"] = "0"
+os.environ["DMN_DYNFILTER_DMA"] = "1"
 B, L, K, C, S = 32, 20, 10, 2696, 256
 g = torch.Generator(device="cuda").manual_seed(1)
 V = torch.randn((B, C, S), device="cuda", generator=g); F = torch.rand((L, B, K, C), device="cuda", generator=g)
