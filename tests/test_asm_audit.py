@@ -75,7 +75,7 @@ def test_audit_flags_the_pattern_that_corrupted_grad_U(tmp_path):
 
 
 _ASM = {}
-_ASM_SOURCES = ["sru_bwd.hip", "sru_fwd_k2.hip", "sru_fwd_k3.hip", "sru_fwd_k4.hip", "mix_sru.hip", "mix.hip", "tapconv.hip"]
+_ASM_SOURCES = ["sru_bwd.hip", "sru_fwd_k2.hip", "sru_fwd_k3.hip", "sru_fwd_k4.hip", "mix_sru.hip", "mix.hip", "tapconv.hip", "dynfilter.hip"]
 
 
 def _asm_of(src, tmp_path_factory):
@@ -159,7 +159,7 @@ def test_sgpr_audit_flags_a_descriptor_written_by_valu_right_before_an_asm_load(
     assert n == 2 and len(bad) == 1 and "s[4]" in bad[0]
 
 
-@pytest.mark.parametrize("src", ["sru_bwd.hip", "sru_fwd_k2.hip", "sru_fwd_k3.hip", "sru_fwd_k4.hip", "mix_sru.hip", "mix.hip"])
+@pytest.mark.parametrize("src", ["sru_bwd.hip", "sru_fwd_k2.hip", "sru_fwd_k3.hip", "sru_fwd_k4.hip", "mix_sru.hip", "mix.hip", "dynfilter.hip"])
 def test_asm_memory_instructions_never_read_an_sgpr_a_valu_wrote_less_than_five_wait_states_ago(src, tmp_path_factory):
     if not os.path.exists(dbuild.HIPCC):
         pytest.skip("hipcc not installed")
