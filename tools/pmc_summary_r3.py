@@ -41,7 +41,7 @@ LABELS = {
     # round 3
     ("dmn::mix_bwd_one_kernel<2>", 262144): ("mix_bcast_add_bwd one pass B=64 S=100 L=20 K=10 M=4020 (gQ once)",
                                          4 * 64 * (100 * 20 * 4020 + 100 * 4020 + 20 * 4020 + 2 * 20 * 10 * 100 + 4020 * 10)),
-    ("dmn::dynfilter_fwd_mfma<false, 32>", 114688): ("dynfilter_fwd MFMA B=32 C=2696 S=256 (MFMA-bound; 32-row tiles, whole contraction per workgroup)",
+    ("dmn::dynfilter_fwd_dma<64, 4>", 131072): ("dynfilter_fwd MFMA B=32 C=2696 S=256 (MFMA-bound; LDS-DMA ring kernel, whole contraction per workgroup)",
                                                  4 * 32 * (2696 * 256 + 200 * 2696 + 200 * 256)),
     ("dmn::bias_sigmoid_kernel<4>", 4423680): ("bias_sigmoid 640 x 26960 in place", 8 * 640 * 26960),
     ("dmn::sru_fwd_cols_img<3, 1, 16>", 32192): ("sru_fwd_image k=3 T=256 cols=32160 (h stored as the (B,Hm,H,W) map)", 20 * 256 * 32160),
