@@ -11,6 +11,7 @@
 // so no permuted copy of the filters is ever made.
 #include "common.h"
 #include "sru_ring.h"
+#include <atomic>
 
 namespace dmn {
 
@@ -660,9 +661,17 @@ static int dynfilter_fwd_impl(const char *fn, const float *V, const float *F, fl
     if (dma_ok && (de ? atoi(de) == 1 : (tiles64 >= NUM_CU && tiles64 < 8 * NUM_CU))) {
         constexpr int D = 4;
         const int ldsb = D * (64 / 8 + 8) * 1024;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(dynfilter_fwd_dma<64, D>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
-        if (e != hipSuccess) return fail((int)e, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
+        // 64 KB of dynamic LDS: opt in once per device (not per launch: a launch may be under stream capture)
+        static std::atomic<unsigned long long> opted{0};
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return fail((int)e, "%s: hipGetDevice: %s", fn, hipGetErrorString(e));
+        if (dev >= 64 || !(opted.load() >> dev & 1ULL)) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(dynfilter_fwd_dma<64, D>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
+            if (e != hipSuccess) return fail((int)e, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
+            if (dev < 64) opted.fetch_or(1ULL << dev);
+        }
         hipLaunchKernelGGL((dynfilter_fwd_dma<64, D>), xcd_grid(tiles64), dim3(256), ldsb, s, V, F, P, B, R, K, C, S, spc);
         return launch_status(fn);
     }

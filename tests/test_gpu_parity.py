@@ -1102,25 +1102,29 @@ def test_dmn_every_inference_shortcut_equals_the_plain_path(high_res, size):
     assert ((fast > 0) == (plain > 0)).float().mean().item() >= 0.999
 
 
-@pytest.mark.parametrize("B,n_words", [(2, 6), (8, 20)])
-def test_graphed_dmn_replay_equals_eager_forward(B, n_words):
+@pytest.mark.parametrize("B,n_words,W", [(2, 6, 96), (8, 20, 96), (16, 20, 128)])
+def test_graphed_dmn_replay_equals_eager_forward(B, n_words, W, monkeypatch):
     """One captured HIP graph per shape: replays must reproduce the eager forward bit for bit,
     for new inputs as well (static buffers), and reject other shapes.  (8 queries of 20 words: the
-    forward contains the fused mix + layer-0 scan on the matrix cores, captured like any other launch.)"""
+    forward contains the fused mix + layer-0 scan on the matrix cores, captured like any other launch;
+    16 queries on a 2 x 4 map with the dynamic filters forced onto the LDS-DMA ring kernel, whose 64 KB
+    LDS opt-in must not happen under capture.)"""
+    if W == 128:
+        monkeypatch.setenv("DMN_DYNFILTER_DMA", "1")
     net = dms_amd.DMN(100, num_filters=10, lang_layers=3, mix_we=True, pretrained=False,
                       high_res=True, upsampling_mode="bilinear", upsampling_amplification=32)
     torch.nn.Module.load_state_dict(net, det_fill_state(net.state_dict()))
     net = net.to(DEV).eval()
-    g = dms_amd.GraphedDMN(net, B, 64, 96, n_words)
+    g = dms_amd.GraphedDMN(net, B, 64, W, n_words)
     for seed in (11, 12):
-        img = det_uniform((B, 3, 64, 96), seed, 1.0).to(DEV)
+        img = det_uniform((B, 3, 64, W), seed, 1.0).to(DEV)
         words = det_ints((B, n_words), seed + 100, 100).to(DEV)
         with torch.no_grad():
             want = net(img, words)
         got = g(img, words).clone()
-        assert got.shape == (B, 1, 64, 96) and torch.equal(got, want)
+        assert got.shape == (B, 1, 64, W) and torch.equal(got, want)
     with pytest.raises(RuntimeError, match="captured for"):
-        g(torch.zeros((1, 3, 64, 96), device=DEV), torch.zeros((1, n_words), dtype=torch.long, device=DEV))
+        g(torch.zeros((1, 3, 64, W), device=DEV), torch.zeros((1, n_words), dtype=torch.long, device=DEV))
 
 
 # ------------------------------------------------------------------------------------
