@@ -211,3 +211,31 @@ def test_bench_gpus_n_without_torchrun_refuses_a_box_with_fewer_devices():
     assert r.returncode != 0
     assert b"GPU(s)" in r.stderr and b"refusing" in r.stderr
     assert not [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+
+
+def test_committed_bench_line_keeps_the_driver_contract():
+    """profiles/r3_bench_n1.json is the line `python bench.py` printed on the MI355X box: the keys the driver and the
+    judge read must all be there, with the relations the contract states (frac = achieved / peak, value * ms_per_step
+    = batch, the CPU leg says what it ran on)."""
+    import json
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r3_bench_n1.json")
+    line = json.loads(open(path).read().strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["higher_is_better"] is True and line["scaling"] == "weak"
+    assert line["vs_baseline"] is None and line["dtype"] == "f32" and line["data"] == "synthetic"
+    assert "workload" in line["config"] and "model" not in line["config"]
+    batch = line["config"]["global_batch"]
+    assert abs(line["value"] * line["ms_per_step"] / 1e3 - batch) < 0.01 * batch
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.0 < r["frac"] < 1.0
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 0.01 * r["achieved"]
+    assert r["traffic"] is None or 0.99 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.2
+    c = line["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert line["collective_ranks"] == 1
+    for shard in ("B=64", "B=128"):
+        assert line["shards"][shard]["finite"] and line["shards"][shard]["rel_diff_vs_same_samples_in_B32"] < 1e-4
+    assert line["train320"]["value"] > 0 and line["train320"]["batch_per_gpu"] == 64
